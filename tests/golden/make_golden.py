@@ -1,0 +1,269 @@
+"""Generate golden vectors by IMPORTING THE REFERENCE in the build container.
+
+Run here (never on the GPU box -- /root/reference does not exist there):
+
+    python tests/golden/make_golden.py
+
+Writes small .npz fixtures next to this file.  Each holds the inputs and the outputs the
+reference's own functions produced for them:
+
+  code/FasterRCNN/RPN/anchor_generator.py  AnchorGenerator            -> anchors.npz
+  code/FasterRCNN/utils.py                 box_iou / tagging_box /
+                                           box_deviation              -> targets.npz
+  code/FasterRCNN/utils.py                 box_regression / box_clip /
+                                           remove_small_box           -> decode.npz
+  code/FasterRCNN/utils.py                 get_sampling_factor        -> sampling.npz
+  RPN/rpn.py:55-83 call sequence replayed with the reference's utils
+  functions and torch.topk (rpn.py itself cannot be imported: it needs
+  torchvision, which is absent)                                        -> rpn_stages.npz
+
+`utils.py` imports cv2 at module level (utils.py:5) only for draw_anchor_box; an empty
+module object is registered under that name so the import succeeds.  Nothing on the hot
+path touches it.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+REF = "/root/reference/code/FasterRCNN"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+warnings.filterwarnings("ignore")
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "RPN"))
+
+import utils as R  # noqa: E402  (the reference's utils.py)
+from anchor_generator import AnchorGenerator  # noqa: E402
+
+
+def checksum(t):
+    return int(t.contiguous().view(torch.int32).to(torch.int64).sum())
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(name, os.path.getsize(path), "bytes")
+
+
+def gen_anchors():
+    out = {}
+    cases = {
+        "smoke": ((2, 256, 256), [(112, 112), (64, 64)], None, None),
+        "cfg1": ((1, 600, 1000), [(37, 62)], None, None),
+        "fpn": ((2, 800, 1344), [(13, 21), (25, 42), (50, 84)], None, None),
+        "small_full": ((3, 64, 96), [(4, 6), (3, 5)], None, None),
+        "custom": ((1, 100, 150), [(7, 9)], ((32,), (64,), (100,)), ((0.5, 1.0, 2.0), (0.25, 1.0, 3.0), (0.7, 1.3, 1.9))),
+    }
+    for name, (info, fsz, sizes, ratios) in cases.items():
+        ag = AnchorGenerator() if sizes is None else AnchorGenerator(sizes, ratios)
+        feats = [torch.zeros(info[0], 1, h, w) for h, w in fsz]
+        res = ag(info, feats)
+        out[f"{name}.info"] = np.asarray(info)
+        out[f"{name}.fsz"] = np.asarray(fsz)
+        out[f"{name}.base"] = ag.base_anchor.numpy()
+        if sizes is not None:
+            out[f"{name}.sizes"] = np.asarray(sizes, np.float32)
+            out[f"{name}.ratios"] = np.asarray(ratios, np.float32)
+        for l, a in enumerate(res):
+            assert a.shape[0] == info[0] and a.shape[2:] == (9, 4)
+            a0 = a[0].contiguous()
+            out[f"{name}.l{l}.checksum"] = np.asarray(checksum(a0))
+            out[f"{name}.l{l}.shape"] = np.asarray(a.shape)
+            if a0.shape[0] <= 64:
+                out[f"{name}.l{l}.full"] = a0.numpy()
+            else:
+                out[f"{name}.l{l}.head"] = a0[:32].numpy()
+                out[f"{name}.l{l}.tail"] = a0[-32:].numpy()
+    save("anchors.npz", **out)
+
+
+def rand_gt(g, m, W=1000.0, H=600.0):
+    w = torch.rand(m, generator=g) * 240 + 16
+    h = torch.rand(m, generator=g) * 240 + 16
+    x1 = torch.rand(m, generator=g) * (W - w)
+    y1 = torch.rand(m, generator=g) * (H - h)
+    return torch.stack([x1, y1, x1 + w, y1 + h], 1)
+
+
+def gen_targets():
+    g = torch.Generator().manual_seed(20211117)
+    ag = AnchorGenerator()
+    anchors = ag((1, 600, 1000), [torch.zeros(1, 1, 37, 62)])[0][0].reshape(-1, 4)
+    out = {}
+    # (name, N, M, neg, pos, with_labels, weights)
+    cases = [
+        ("m1", 2048, 1, 0.3, 0.7, False, None),
+        ("m2", 2048, 2, 0.3, 0.7, True, [10.0, 10.0, 5.0, 5.0]),
+        ("m100", 1536, 100, 0.3, 0.7, False, None),
+        ("m100w", 1024, 100, 0.5, 0.5, True, [10.0, 10.0, 5.0, 5.0]),
+        ("m7swap", 512, 7, 0.6, 0.4, True, None),  # pos < neg: assignment order matters
+    ]
+    for name, N, M, neg, pos, with_labels, weights in cases:
+        sel = torch.randperm(anchors.shape[0], generator=g)[:N].sort().values
+        box1 = anchors[sel].clone()
+        box2 = rand_gt(g, M)
+        if M >= 2:
+            box2[1] = box2[0]  # duplicate GT: first-max tie rule
+        # adversarial rows
+        box1[0] = box2[0]  # IoU == 1
+        box1[1] = torch.tensor([2000.0, 2000.0, 2100.0, 2100.0])  # IoU == 0 with every GT
+        box1[2] = torch.tensor([10.0, 10.0, 10.0, 10.0])  # zero area
+        # exact threshold hit: GT0 = [x,y,x+w,y+h]; box with same x-range and half the height -> IoU 0.5
+        x1, y1, x2, y2 = box2[0].tolist()
+        box1[3] = torch.tensor([x1, y1, x2, y1 + (y2 - y1) / 2])
+        labels = (torch.randint(1, 21, (M,), generator=g).float()) if with_labels else None
+        iou = R.box_iou(box1, box2)
+        lab = R.tagging_box(box1, box2, neg, pos, labels)
+        dev = R.box_deviation(box1, box2, weights)
+        mx, arg = iou.max(dim=1)
+        out[f"{name}.box1"] = box1.numpy()
+        out[f"{name}.box2"] = box2.numpy()
+        out[f"{name}.thr"] = np.asarray([neg, pos], np.float64)
+        if labels is not None:
+            out[f"{name}.labels"] = labels.numpy()
+        if weights is not None:
+            out[f"{name}.weights"] = np.asarray(weights, np.float32)
+        if N * M <= 1536 * 100:
+            out[f"{name}.iou"] = iou.numpy()
+        out[f"{name}.max"] = mx.numpy()
+        out[f"{name}.argmax"] = arg.numpy()
+        out[f"{name}.label"] = lab.numpy()
+        out[f"{name}.dev"] = dev.numpy()
+    # degenerate pairs: 0/0 -> NaN (box_iou has no epsilon); NaN rows keep label 0
+    box1 = torch.tensor([[5.0, 5.0, 5.0, 5.0], [0.0, 0.0, 10.0, 10.0], [1.0, 1.0, 1.0, 9.0]])
+    box2 = torch.tensor([[0.0, 0.0, 4.0, 4.0], [5.0, 5.0, 5.0, 5.0], [2.0, 2.0, 8.0, 8.0]])
+    iou = R.box_iou(box1, box2)
+    mx, arg = iou.max(dim=1)
+    out["nan.box1"] = box1.numpy()
+    out["nan.box2"] = box2.numpy()
+    out["nan.iou"] = iou.numpy()
+    out["nan.max"] = mx.numpy()
+    out["nan.argmax"] = arg.numpy()
+    out["nan.label"] = R.tagging_box(box1, box2, 0.3, 0.7).numpy()
+    out["nan.thr"] = np.asarray([0.3, 0.7])
+    save("targets.npz", **out)
+
+
+def gen_decode():
+    g = torch.Generator().manual_seed(777)
+    ag = AnchorGenerator()
+    anchors = ag((1, 600, 1000), [torch.zeros(1, 1, 37, 62)])[0][0].reshape(-1, 4)
+    n = 4096
+    sel = torch.randperm(anchors.shape[0], generator=g)[:n]
+    box = anchors[sel].clone()
+    out = {}
+    for K in (1, 3):
+        regs = torch.randn(n, 4 * K, generator=g)
+        regs[:, 0::4] *= 0.1
+        regs[:, 1::4] *= 0.1
+        regs[:, 2::4] *= 0.2
+        regs[:, 3::4] *= 0.2
+        regs[0, 2::4] = 9.0  # above the log(1000/16) clamp
+        regs[1, 3::4] = 4.135166556742356
+        regs[2, :] = 0.0
+        regs[3, 2::4] = -30.0  # collapses the width
+        dec = R.box_regression(box, regs)
+        out[f"k{K}.box"] = box.numpy()
+        out[f"k{K}.regs"] = regs.numpy()
+        out[f"k{K}.decoded"] = dec.numpy()
+    # clip + small-box filter on wider-ranging boxes
+    raw = (torch.rand(n, 4, generator=g) - 0.25) * torch.tensor([1400.0, 900.0, 1400.0, 900.0])
+    raw[0] = torch.tensor([-5.0, -7.0, 1000.0, 600.0])
+    raw[1] = torch.tensor([1000.0, 600.0, 1001.0, 601.0])
+    raw[2] = torch.tensor([10.0, 10.0, 10.001, 20.0])  # w == 1e-3 (fp32) edge: strict >
+    raw[3] = torch.tensor([10.0, 10.0, 10.0 + 2e-3, 20.0])
+    clipped = R.box_clip(raw, (600, 1000))
+    out["clip.in"] = raw.numpy()
+    out["clip.image_size"] = np.asarray([600, 1000])
+    out["clip.out"] = clipped.numpy()
+    for t in (1e-3, 16.0):
+        kept, idx = R.remove_small_box(clipped, t)
+        out[f"small.{t}.index"] = idx.numpy()
+        out[f"small.{t}.box"] = kept.numpy()
+    save("decode.npz", **out)
+
+
+def gen_sampling():
+    out = {}
+    cases = [(256, 0.5, 40, 18000), (256, 0.5, 300, 18000), (128, 0.25, 10, 1500), (512, 0.25, 0, 60),
+             (256, 0.5, 3, 5)]
+    for i, (S, f, npos, nneg) in enumerate(cases):
+        torch.manual_seed(1234 + i)
+        pf, nf = R.get_sampling_factor(S, f, npos, nneg)
+        out[f"c{i}.args"] = np.asarray([S, f, npos, nneg], np.float64)
+        out[f"c{i}.seed"] = np.asarray(1234 + i)
+        out[f"c{i}.pos"] = pf.numpy()
+        out[f"c{i}.neg"] = nf.numpy()
+    save("sampling.npz", **out)
+
+
+def tie_free_scores(g, shape_bahw):
+    B, A_, H, W = shape_bahw
+    n = A_ * H * W
+    s = torch.stack([((torch.randperm(n, generator=g).float() / n) - 0.5) * 8 for _ in range(B)])
+    return s.reshape(B, H, W, A_).permute(0, 3, 1, 2).contiguous()
+
+
+def gen_rpn_stages():
+    """Replay RPN/rpn.py:55-83 (everything before the torchvision nms call) with the
+    reference's own utils functions and torch.topk on tie-free logits."""
+    g = torch.Generator().manual_seed(4242)
+    info = (2, 192, 320)
+    fsz = [(12, 20), (6, 10)]
+    ag = AnchorGenerator()
+    feats = [torch.zeros(info[0], 1, h, w) for h, w in fsz]
+    list_anchors = ag(info, feats)
+    list_cls = [tie_free_scores(g, (info[0], 9, h, w)) for h, w in fsz]
+    # make scores distinct ACROSS levels too: shift level 1 by an irrational-ish offset
+    list_cls[1] = list_cls[1] + 0.000123
+    list_regs = []
+    for h, w in fsz:
+        r = torch.randn(info[0], 36, h, w, generator=g)
+        r[:, 0::4] *= 0.1
+        r[:, 1::4] *= 0.1
+        r[:, 2::4] *= 0.2
+        r[:, 3::4] *= 0.2
+        list_regs.append(r)
+    num_pre_nms, min_size = 1000, 1e-3
+    anchors = torch.cat([a.flatten(1, 2) for a in list_anchors], dim=1)
+    cls = torch.cat([c.permute(0, 2, 3, 1).flatten(1, 3) for c in list_cls], dim=1)
+    reg = torch.cat([r.permute(0, 2, 3, 1).flatten(1, 2) for r in list_regs], dim=1)
+    assert all(len(torch.unique(cls[b])) == cls.shape[1] for b in range(info[0])), "scores must be tie-free"
+    out = {"info": np.asarray(info), "fsz": np.asarray(fsz), "num_pre_nms": np.asarray(num_pre_nms),
+           "min_size": np.asarray(min_size)}
+    for l in range(len(fsz)):
+        out[f"cls{l}"] = list_cls[l].numpy()
+        out[f"reg{l}"] = list_regs[l].numpy()
+    for b, (image_score, image_reg, image_anchor) in enumerate(zip(cls, reg, anchors)):
+        k = min(num_pre_nms, image_score.size(0))
+        _, top_index = torch.topk(image_score, k=k)
+        top_cls = image_score[top_index]
+        top_reg = image_reg.view(-1, 4)[top_index]
+        top_anchor = image_anchor[top_index]
+        proposal = R.box_regression(top_anchor, top_reg)
+        clipped = R.box_clip(proposal, (info[1], info[2]))
+        kept, index = R.remove_small_box(clipped, min_size)
+        out[f"b{b}.top_index"] = top_index.numpy()
+        out[f"b{b}.top_score"] = top_cls.numpy()
+        out[f"b{b}.decoded"] = proposal.numpy()
+        out[f"b{b}.clipped"] = clipped.numpy()
+        out[f"b{b}.small_index"] = index.numpy()
+        out[f"b{b}.filtered"] = kept.numpy()
+        out[f"b{b}.filtered_score"] = top_cls[index].numpy()
+    save("rpn_stages.npz", **out)
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference not present: goldens can only be generated in the build container")
+    gen_anchors()
+    gen_targets()
+    gen_decode()
+    gen_sampling()
+    gen_rpn_stages()
