@@ -1,0 +1,161 @@
+/*
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so: the MI355X (gfx950) kernels behind the Faster R-CNN
+ * region-proposal / RoI hot path of DingLuBJUT/ObjectDetection (code/FasterRCNN).
+ *
+ * The reference is pure Python and has no FFI of its own: each entry point below
+ * replaces the torch / torchvision call sequence at the cited reference lines (paths relative to
+ * code/FasterRCNN/) and is what the Python drop-in package `objectdetection_amd` binds with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - the caller owns every buffer, workspace included (query the *_workspace_bytes functions);
+ *     no entry point allocates, frees or synchronises -- all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - fp32 everywhere, boxes are [x1, y1, x2, y2], index outputs are int32 unless stated;
+ *   - return value: 0 on success, a negative FRCNN_E* code otherwise (never throws);
+ *     frcnn_last_error_string() describes the last failure on the calling thread;
+ *   - IoU is evaluated in fp32 exactly as utils.py:119 associates it,
+ *     inter / ((area_a + area_b) - inter), with IEEE division and no FMA contraction.
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK 0
+#define FRCNN_EINVAL (-1)    /* bad argument (shape, null pointer, size limit) */
+#define FRCNN_EWORKSPACE (-2) /* workspace too small */
+#define FRCNN_ELAUNCH (-3)   /* HIP reported a launch error */
+
+int frcnn_abi_version(void);
+const char *frcnn_last_error_string(void);
+
+/* ---- K1 anchors ------------------------------------------------------------------------------
+ * RPN/anchor_generator.py:43-64 (get_base_anchor).  HOST arithmetic on 4*na floats:
+ * h = size, w = size*ratio (fp32), out = [-w,-h,w,h]/2.  All pointers are host pointers. */
+int frcnn_base_anchors_f32(const float *size_host, const float *ratio_host, int na, float *out_host);
+
+/* RPN/anchor_generator.py:66-95 (generate_anchor), one pyramid level:
+ * out[(y*fw+x), a, :] = [x*sx, y*sy, x*sx, y*sy] + base[a, :]   (two fp32 roundings).
+ * base: (na,4) device.  out: (fh*fw, na, 4). */
+int frcnn_anchor_grid_f32(const float *base, int na, int fh, int fw, float stride_y, float stride_x,
+                          float *out, void *stream);
+
+/* ---- K2 flatten + top-k ----------------------------------------------------------------------
+ * RPN/rpn.py:56-57: cls (B,na,h,w) -> scores[b, level_offset + (y*w+x)*na + a];
+ * reg (B,4na,h,w) -> deltas[b, level_offset + (y*w+x)*na + a, 0:4].  One call per level.
+ * scores: (B, A_total), deltas: (B, A_total, 4). */
+int frcnn_rpn_flatten_f32(const float *cls, const float *reg, int B, int na, int h, int w,
+                          int level_offset, int A_total, float *scores, float *deltas, void *stream);
+
+/* RPN/rpn.py:65-66: per-row torch.topk(score, k), sorted.  Order: descending score, ties by
+ * ascending index; NaN ranks above +inf; -0.0 below +0.0 (torch leaves tie order undefined).
+ * scores: (B, n).  val_out: (B, k) fp32 (may be NULL).  idx_out: (B, k) int32.  k <= n. */
+size_t frcnn_topk_workspace_bytes(int B, int n, int k);
+int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, float *val_out, int32_t *idx_out,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- K3 decode / clip / small-box filter -----------------------------------------------------
+ * utils.py:173-208 (box_regression, incl. quirk Q1: centre = (w/2, h/2)).
+ * box: (n,4); regs: (n,4K) as [dx,dy,dw,dh]xK; out: (n,4K) as [x1,y1,x2,y2]xK. */
+int frcnn_box_regression_f32(const float *box, const float *regs, int n, int K, float *out,
+                             void *stream);
+
+/* utils.py:242-259 (box_clip): x to [0,image_w], y to [0,image_h] (inclusive). */
+int frcnn_box_clip_f32(const float *box, int n, float image_h, float image_w, float *out,
+                       void *stream);
+
+/* utils.py:231-239 (remove_small_box, size part): keeps rows with w > t AND h > t in ascending
+ * order.  box_out: (n,4) (first *count rows valid); index_out: (n) int64; count_out: (1) int32. */
+int frcnn_remove_small_box_f32(const float *box, int n, float size_thresh, float *box_out,
+                               int64_t *index_out, int32_t *count_out, void *stream);
+
+/* utils.py:227-229 / ROIHead/roi_head.py:197,209: index = where(value > thresh)[0], ascending.
+ * index_out: (n) int64; count_out: (1) int32. */
+int frcnn_select_gt_f32(const float *value, int n, float thresh, int64_t *index_out,
+                        int32_t *count_out, void *stream);
+
+/* Fused RPN/rpn.py:67-69,75,81-83 for a whole batch: gather anchor+delta by top-k index, decode,
+ * clip to (image_h,image_w), drop boxes with w<=t or h<=t, order preserved.
+ * anchors: (A,4) shared by the batch when anchor_batch_stride == 0, else (B,A,4) with that
+ * element stride; deltas: (B,A,4); top_idx/top_score: (B,k).
+ * boxes_out: (B,k,4); scores_out: (B,k); src_out: (B,k) position in the top-k list of each kept
+ * row (= remove_small_box's index); count_out: (B) kept rows per image. */
+int frcnn_decode_clip_filter_f32(const float *anchors, int64_t anchor_batch_stride,
+                                 const float *deltas, const int32_t *top_idx,
+                                 const float *top_score, int B, int A, int k, float image_h,
+                                 float image_w, float min_size, float *boxes_out,
+                                 float *scores_out, int32_t *src_out, int32_t *count_out,
+                                 void *stream);
+
+/* ---- K4 NMS ----------------------------------------------------------------------------------
+ * torchvision.ops.nms as called at RPN/rpn.py:84 and ROIHead/roi_head.py:215, batched.
+ * boxes: (B, max_n, 4), each image's rows ALREADY in candidate order (descending score);
+ * n_per_image: (B) int32 device, or NULL for max_n everywhere.  Box j is suppressed by an earlier
+ * kept box i when (double)iou_f32(i,j) > iou_threshold; NaN never suppresses.  Stops after
+ * max_keep keeps (the reference's [:num_post_nms]).
+ * keep_out: (B, max_keep) positions into the image's rows, in keep order; n_keep_out: (B). */
+size_t frcnn_nms_workspace_bytes(int B, int max_n);
+int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
+                         double iou_threshold, int max_keep, int32_t *keep_out,
+                         int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* out[b, j, :] = src[b, idx[b, j], :] for j < count[b], zeros for count[b] <= j < m
+ * (proposal[nms_index], RPN/rpn.py:85).  src: (B, n, 4); idx: (B, m); count: (B) or NULL (= m). */
+int frcnn_gather_boxes_f32(const float *src, const int32_t *idx, const int32_t *count, int B, int n,
+                           int m, float *out, void *stream);
+
+/* ---- K5 IoU / target labelling ---------------------------------------------------------------
+ * utils.py:93-120 (box_iou): out (n,m) materialised. */
+int frcnn_box_iou_f32(const float *box1, int n, const float *box2, int m, float *out, void *stream);
+
+/* Fused utils.tagging_box (utils.py:261-291) + utils.box_deviation (utils.py:123-171), batched
+ * as driven by RPN/rpn.py:105-112 and ROIHead/roi_head.py:99-110.
+ * box1: (N,4) shared when box1_batch_stride == 0, else (B,N,4) with that element stride;
+ * box2: (B, m_max, 4) with m_per_image (B) valid rows each (NULL = m_max; every image needs >=1);
+ * labels: (B, m_max) fp32 class ids or NULL (positives get 1); weights_host: 4 floats or NULL.
+ * Row max follows torch.max(dim=1): first maximum wins, the first NaN wins outright.
+ * Outputs (each may be NULL): label (B,N) fp32; argmax (B,N) int32; max_iou (B,N); dev (B,N,4). */
+int frcnn_iou_label_encode_f32(const float *box1, int64_t box1_batch_stride, const float *box2,
+                               const int32_t *m_per_image, const float *labels, int B, int N,
+                               int m_max, float neg_threshold, float pos_threshold,
+                               const float *weights_host, float *label_out, int32_t *argmax_out,
+                               float *max_iou_out, float *dev_out, void *stream);
+
+/* ---- K6 / K7 RoI pooling ---------------------------------------------------------------------
+ * rois[(b,j)] = [b, props[b,j,:]] compacted over images (MultiScaleRoIAlign's roi format,
+ * ROIHead/roi_pooling.py:51-53).  props: (B,P,4); count: (B) or NULL; rois_out: (B*P,5);
+ * total_out: (1) int32 = sum(count). */
+int frcnn_build_rois_f32(const float *props, const int32_t *count, int B, int P, float *rois_out,
+                         int32_t *total_out, void *stream);
+
+/* torchvision LevelMapper: clamp(floor(4 + log2(sqrt(area)/224) + 1e-6), k_min, k_max) - k_min;
+ * NaN -> -1.  rois: (K,5); n_rois: device int32 row count or NULL (= K). */
+int frcnn_level_map_f32(const float *rois, const int32_t *n_rois, int K, int k_min, int k_max,
+                        int32_t *lvl_out, void *stream);
+
+/* torchvision roi_align (aligned=False) on one level.  feat: (B,C,H,W); rois: (K,5);
+ * rows with lvl[r] != lvl_value are skipped when lvl != NULL; rows >= *n_rois are skipped when
+ * n_rois != NULL.  out: (K,C,pooled_h,pooled_w) -- untouched rows keep their previous contents
+ * (the multi-level wrapper zero-fills first, as torchvision does). */
+int frcnn_roi_align_f32(const float *feat, int B, int C, int H, int W, const float *rois,
+                        const int32_t *n_rois, int K, int pooled_h, int pooled_w,
+                        float spatial_scale, int sampling_ratio, const int32_t *lvl, int lvl_value,
+                        float *out, void *stream);
+
+/* torchvision roi_pool (max) -- north_star extra, not called by the reference.
+ * out: (K,C,ph,pw) fp32; argmax: (K,C,ph,pw) int32 flat index h*W+w, -1 for an empty bin. */
+int frcnn_roi_pool_f32(const float *feat, int B, int C, int H, int W, const float *rois, int K,
+                       int pooled_h, int pooled_w, float spatial_scale, float *out, int32_t *argmax,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */

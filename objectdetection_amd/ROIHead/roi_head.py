@@ -1,0 +1,118 @@
+"""ROIHead with the reference's interface (ROIHead/roi_head.py:42-231).
+
+Hot-path parts run on the gfx950 kernels: proposal-target creation (roi_head.py:98-125: fused
+IoU / label / encode for the whole batch), RoI pooling (roi_head.py:127-130) and the eval
+post-process (roi_head.py:167-229: decode, clip, score / size / label filters, class-agnostic
+NMS).  The dense heads (mlp_head, predictor) and the losses stay stock PyTorch.
+
+Quirk Q8: the reference calls self.train(mode=False) at roi_head.py:90, so its training branch is
+dead code.  params['force_eval'] (default True) reproduces that; pass False to run the training
+branch as written.
+"""
+import torch
+import torch.nn.functional as F
+from torch.nn import Module
+
+from .. import ops
+from ..utils import get_sampling_factor, remove_small_box, smooth_l1_loss
+
+
+class ROIHead(Module):
+    def __init__(self, params):
+        super().__init__()
+        self.roi_pooling = params['roi_pooling']
+        self.mlp_head = params['mlp_head']
+        self.predictor = params['predictor']
+        self.pos_threshold = params['pos_threshold']
+        self.neg_threshold = params['neg_threshold']
+        self.num_sample = params['num_sample']
+        self.pos_fraction = params['pos_fraction']
+        self.regression_weights = params['regression_weights']
+        self.score_thresh = params['score_thresh']
+        self.proposal_min_size = params['proposal_min_size']
+        self.nms_threshold = params['nms_threshold']
+        self.num_post_nms = params['num_post_nms']
+        self.force_eval = params.get('force_eval', True)
+
+    # -- proposal targets: roi_head.py:99-110, batched -------------------------------------------
+    def proposal_targets(self, list_rpn_proposals, list_targets, device):
+        """-> list over images of (cls_label (P_i,), reg_label (P_i,4))."""
+        B = len(list_rpn_proposals)
+        P = max(p.shape[0] for p in list_rpn_proposals)
+        m = [len(t['box']) for t in list_targets]
+        M = max(m)
+        props = torch.zeros((B, P, 4), dtype=torch.float32, device=device)
+        gt = torch.zeros((B, M, 4), dtype=torch.float32)
+        lab = torch.zeros((B, M), dtype=torch.float32)
+        for i, (p, t) in enumerate(zip(list_rpn_proposals, list_targets)):
+            props[i, :p.shape[0]] = p.detach()
+            gt[i, :m[i]] = torch.as_tensor(t['box'], dtype=torch.float32).reshape(-1, 4)
+            cls = torch.as_tensor(t['class'], dtype=torch.float32).reshape(-1)
+            lab[i, :cls.shape[0]] = cls
+        out = ops.iou_label_encode(props, gt.to(device), torch.tensor(m, dtype=torch.int32, device=device),
+                                   self.neg_threshold, self.pos_threshold, lab.to(device), self.regression_weights,
+                                   want=("label", "dev"))
+        return [(out["label"][i, :p.shape[0]], out["dev"][i, :p.shape[0]]) for i, p in enumerate(list_rpn_proposals)]
+
+    def forward(self, list_rpn_proposals, list_features, batch_image_info, list_targets, list_image_size):
+        if self.force_eval:
+            self.train(mode=False)  # roi_head.py:90 (Q8)
+        image_height = batch_image_info[1]
+        image_width = batch_image_info[2]
+        device = list_rpn_proposals[0].device
+
+        list_cls_label, list_reg_label, list_proposals = [], [], []
+        if self.training:
+            targets = self.proposal_targets(list_rpn_proposals, list_targets, device)
+            for proposal, (cls_label, reg_label) in zip(list_rpn_proposals, targets):
+                pos_index = torch.where(torch.gt(cls_label, 0))[0]                 # roi_head.py:113
+                neg_index = torch.where(torch.eq(cls_label, 0))[0]                 # roi_head.py:114
+                pos_factor, neg_factor = get_sampling_factor(self.num_sample, self.pos_fraction,
+                                                             pos_index.size(0), neg_index.size(0))
+                random_index = torch.cat([neg_index[neg_factor.to(device)], pos_index[pos_factor.to(device)]])
+                list_cls_label.append(cls_label[random_index])
+                list_reg_label.append(reg_label[random_index])
+                list_proposals.append(proposal[random_index])
+            list_rpn_proposals = list_proposals
+
+        dict_feature = dict(zip([str(i + 1) for i in range(len(list_features))], list_features))
+        roi_features = self.roi_pooling(dict_feature, list_rpn_proposals, [(image_height, image_width)])
+        mlp_features = self.mlp_head(roi_features)
+        predict_cls, predict_reg = self.predictor(mlp_features)
+        predict_reg = predict_reg.view(predict_cls.size(0), -1, 4)
+
+        roi_loss = {}
+        result = []
+        if self.training:
+            cls_label = torch.cat(list_cls_label)
+            reg_label = torch.cat(list_reg_label)
+            cls_loss = F.cross_entropy(predict_cls, cls_label.long())
+            pos_index = torch.where(torch.gt(cls_label, 0))[0]
+            pos_index_label = cls_label[pos_index].long()
+            reg_loss = smooth_l1_loss(predict_reg[pos_index, pos_index_label], reg_label[pos_index])
+            roi_loss = {"cls_loss": cls_loss, "reg_loss": reg_loss}
+        else:
+            # roi_head.py:167-229
+            num_class = predict_cls.size(-1)
+            predict_score = F.softmax(predict_cls, -1)
+            num_per_image = [p.size(0) for p in list_rpn_proposals]
+            list_score = torch.split(predict_score, num_per_image)
+            list_reg = torch.split(predict_reg, num_per_image)
+            for i in range(len(list_rpn_proposals)):
+                proposal = list_rpn_proposals[i]
+                score = list_score[i]
+                label = torch.arange(num_class, device=device)[None, :].expand_as(score)
+                proposal = ops.box_regression(proposal, list_reg[i].flatten(1, 2)).view(-1, 4)
+                proposal = ops.box_clip(proposal, list_image_size[i][0], list_image_size[i][1])
+                score = score.detach().flatten()
+                label = label.flatten()
+                index, count = ops.select_gt(score, self.score_thresh)               # roi_head.py:197
+                index = index[:int(count.item())]
+                proposal, score, label = proposal[index], score[index], label[index]
+                _, index = remove_small_box(proposal, self.proposal_min_size)         # roi_head.py:203
+                proposal, score, label = proposal[index], score[index], label[index]
+                index = torch.where(torch.gt(label, 0))[0]                            # roi_head.py:209
+                proposal, score, label = proposal[index], score[index], label[index]
+                index = ops.nms(proposal, score, self.nms_threshold)[:self.num_post_nms]  # roi_head.py:215
+                result.append({'proposal': proposal[index], 'score': score[index], 'label': label[index]})
+        return result, roi_loss

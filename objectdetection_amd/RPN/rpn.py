@@ -1,0 +1,111 @@
+"""RPN stage with the reference's interface (RPN/rpn.py:31-142).
+
+`RPN(dict_params).forward(batch_image_info, list_features, list_targets)` returns
+`(list_nms_proposals, rpn_loss)` exactly like the reference, but the whole proposal path of
+RPN/rpn.py:54-85 runs as six batched kernel launches (flatten -> top-k -> decode/clip/filter ->
+NMS mask -> NMS scan -> gather) instead of three per-image Python loops, and the anchor-target
+path of RPN/rpn.py:105-112 is one fused IoU/label/encode launch for the batch.
+
+`proposals_padded` is the sync-free form used by the benchmark and by ROIHead's batched path: it
+returns the padded (B, num_post_nms, 4) tensor and the per-image counts without touching the host.
+"""
+import torch
+from torch.nn import Module
+from torch.nn import functional as F
+
+from .. import ops
+from ..utils import get_sampling_factor, smooth_l1_loss
+
+
+class RPN(Module):
+    def __init__(self, dict_params):
+        super().__init__()
+        self.anchor_generator = dict_params['anchor_generator']
+        self.rpn_head = dict_params['rpn_head']
+        self.num_pre_nms = dict_params['num_pre_nms']
+        self.num_post_nms = dict_params['num_post_nms']
+        self.nms_threshold = dict_params['nms_threshold']
+        self.proposal_min_size = dict_params['proposal_min_size']
+        self.pos_threshold = dict_params['pos_threshold']
+        self.neg_threshold = dict_params['neg_threshold']
+        self.num_sample = dict_params['num_sample']
+        self.pos_fraction = dict_params['pos_fraction']
+
+    # -- anchors ---------------------------------------------------------------------------------
+    def _flat_anchors(self, batch_image_info, list_features):
+        """(A,4) anchors shared by the batch when the generator returns stride-0 expands (ours and
+        the reference's do, anchor_generator.py:119); otherwise a contiguous (B,A,4)."""
+        list_anchors = self.anchor_generator(batch_image_info, list_features)
+        if all(a.stride(0) == 0 for a in list_anchors):
+            return list_anchors, torch.cat([a[0].reshape(-1, 4) for a in list_anchors], dim=0)
+        return list_anchors, torch.cat([a.flatten(1, 2) for a in list_anchors], dim=1).contiguous()
+
+    # -- proposal half: RPN/rpn.py:54-85 ----------------------------------------------------------
+    def proposals_from_head(self, batch_image_info, anchors, list_cls, list_regs):
+        """-> (props (B,P,4) zero-padded, n_keep (B) int32) on device, no host sync."""
+        scores, deltas = ops.rpn_flatten(list_cls, list_regs)                   # rpn.py:56-57
+        k = min(self.num_pre_nms, scores.shape[1])                             # rpn.py:65
+        top_val, top_idx = ops.topk_desc(scores, k)                            # rpn.py:66-67
+        boxes, _, _, count = ops.decode_clip_filter(                           # rpn.py:68-69,75,81-83
+            anchors, deltas, top_idx, top_val, batch_image_info[1], batch_image_info[2], self.proposal_min_size)
+        keep, n_keep = ops.nms_sorted(boxes, count, self.nms_threshold, self.num_post_nms)  # rpn.py:84
+        props = ops.gather_boxes(boxes, keep, n_keep)                          # rpn.py:85
+        return props, n_keep
+
+    def proposals_padded(self, batch_image_info, list_features):
+        _, anchors = self._flat_anchors(batch_image_info, list_features)
+        list_cls, list_regs = self.rpn_head(list_features)
+        return self.proposals_from_head(batch_image_info, anchors, list_cls, list_regs)
+
+    # -- anchor-target half: RPN/rpn.py:88-133 ----------------------------------------------------
+    def anchor_targets(self, anchors, list_targets, device):
+        """Batched tagging_box + box_deviation (rpn.py:105-112) -> label (B,A), reg_label (B,A,4)."""
+        B = len(list_targets)
+        m = [len(t['box']) for t in list_targets]
+        gt = torch.zeros((B, max(m), 4), dtype=torch.float32)
+        for i, t in enumerate(list_targets):
+            gt[i, :m[i]] = torch.tensor(t['box'], dtype=torch.float32).reshape(-1, 4)
+        gt = gt.to(device)
+        m_dev = torch.tensor(m, dtype=torch.int32, device=device)
+        out = ops.iou_label_encode(anchors, gt, m_dev, self.neg_threshold, self.pos_threshold, None, None,
+                                   want=("label", "dev"))
+        return out["label"], out["dev"]
+
+    def forward(self, batch_image_info, list_features, list_targets):
+        batch_size = batch_image_info[0]
+        device = list_features[0].device
+        list_anchors, anchors = self._flat_anchors(batch_image_info, list_features)
+        list_cls, list_regs = self.rpn_head(list_features)
+
+        props, n_keep = self.proposals_from_head(batch_image_info, anchors, list_cls, list_regs)
+        counts = n_keep.tolist()  # the reference's ragged list output needs the sizes on the host
+        list_nms_proposals = [props[b, :counts[b]] for b in range(batch_size)]
+
+        rpn_loss = None
+        if self.training:
+            # stock, differentiable views of the head outputs for the loss (rpn.py:90-98)
+            scores = torch.cat([c.permute(0, 2, 3, 1).flatten(1, 3) for c in list_cls], dim=1)
+            regs = torch.cat([r.permute(0, 2, 3, 1).flatten(1, 2).reshape(batch_size, -1, 4) for r in list_regs],
+                             dim=1)
+            labels, reg_labels = self.anchor_targets(anchors, list_targets, device)
+            list_reg_label, list_reg_prediction, list_cls_label, list_cls_prediction = [], [], [], []
+            for b in range(batch_size):
+                cls_label = labels[b]
+                neg_index = torch.where(torch.eq(cls_label, 0))[0]                # rpn.py:115
+                pos_index = torch.where(torch.eq(cls_label, 1))[0]                # rpn.py:116
+                pos_factor, neg_factor = get_sampling_factor(self.num_sample, self.pos_fraction,
+                                                             pos_index.size(0), neg_index.size(0))
+                random_index = torch.cat([neg_index[neg_factor.to(device)], pos_index[pos_factor.to(device)]])
+                list_reg_label.append(reg_labels[b][random_index])
+                list_cls_label.append(cls_label[random_index])
+                list_reg_prediction.append(regs[b][random_index])
+                list_cls_prediction.append(scores[b][random_index])
+            reg_label = torch.cat(list_reg_label)
+            reg_y = torch.cat(list_reg_prediction)
+            cls_label = torch.cat(list_cls_label)
+            cls_y = torch.cat(list_cls_prediction)
+            rpn_loss = {
+                "cls_loss": F.binary_cross_entropy_with_logits(cls_y, cls_label),  # rpn.py:136
+                "reg_loss": smooth_l1_loss(reg_y, reg_label),                       # rpn.py:137 (Q7)
+            }
+        return list_nms_proposals, rpn_loss

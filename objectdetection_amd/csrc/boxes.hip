@@ -1,0 +1,441 @@
+// boxes.hip -- anchors (K1), decode / clip / filter (K3), gather, IoU and target labelling (K5).
+// All of these are HBM-/latency-bound elementwise or row-wise kernels: one 16-B box per lane,
+// float4 loads and stores, batch dimension in the grid so B images are one launch.
+#include <stdarg.h>
+#include <math.h>
+
+#include "common.h"
+
+// ---- error plumbing ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void frcnn_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *frcnn_last_error_string(void) { return g_err; }
+extern "C" int frcnn_abi_version(void) { return 1; }
+
+// ---- K1 anchors -------------------------------------------------------------------------------
+extern "C" int frcnn_base_anchors_f32(const float *size_host, const float *ratio_host, int na,
+                                      float *out_host)
+{
+    FRCNN_REQUIRE(size_host && ratio_host && out_host && na > 0, "base_anchors: bad arguments");
+    for (int a = 0; a < na; ++a) {
+        volatile float h = size_host[a];
+        volatile float w = size_host[a] * ratio_host[a];
+        out_host[4 * a + 0] = -w / 2.0f;
+        out_host[4 * a + 1] = -h / 2.0f;
+        out_host[4 * a + 2] = w / 2.0f;
+        out_host[4 * a + 3] = h / 2.0f;
+    }
+    return FRCNN_OK;
+}
+
+// One lane per anchor (16-B float4 store, fully coalesced: out is (cells, na, 4) row-major).
+__global__ void __launch_bounds__(256) anchor_grid_kernel(const float4 *__restrict__ base, int na,
+                                                          int fw, int total, float sy, float sx,
+                                                          float4 *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int cell = i / na;
+    int a = i - cell * na;
+    int y = cell / fw;
+    int x = cell - y * fw;
+    float gx = (float)x * sx;
+    float gy = (float)y * sy;
+    float4 b = base[a];
+    out[i] = make_float4(gx + b.x, gy + b.y, gx + b.z, gy + b.w);
+}
+
+extern "C" int frcnn_anchor_grid_f32(const float *base, int na, int fh, int fw, float stride_y,
+                                     float stride_x, float *out, void *stream)
+{
+    FRCNN_REQUIRE(base && out && na > 0 && fh > 0 && fw > 0, "anchor_grid: bad arguments");
+    long long total = (long long)fh * fw * na;
+    FRCNN_REQUIRE(total < (1ll << 31), "anchor_grid: too many anchors");
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(anchor_grid_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)base, na, fw, (int)total, stride_y, stride_x, (float4 *)out);
+    FRCNN_CHECK_LAUNCH("anchor_grid");
+    return FRCNN_OK;
+}
+
+// ---- K3 elementwise pieces --------------------------------------------------------------------
+__device__ __forceinline__ float4 decode_one(float4 box, float4 d, float clampv)
+{
+    // utils.py:186-204.  Quirk Q1: the centre is (w/2, h/2); the box origin is not added.
+    float bh = box.w - box.y;
+    float bw = box.z - box.x;
+    float cx = bw / 2.0f;
+    float cy = bh / 2.0f;
+    float dw = d.z > clampv ? clampv : d.z;
+    float dh = d.w > clampv ? clampv : d.w;
+    float px = cx + d.x * bw;
+    float py = cy + d.y * bh;
+    float ph = expf(dh) * bh;
+    float pw = expf(dw) * bw;
+    return make_float4(px - pw / 2.0f, py - ph / 2.0f, px + pw / 2.0f, py + ph / 2.0f);
+}
+
+__device__ __forceinline__ float clip1(float v, float hi)
+{
+    v = v < 0.0f ? 0.0f : v;
+    v = v > hi ? hi : v;
+    return v;
+}
+
+__device__ __forceinline__ float4 clip_box(float4 b, float image_h, float image_w)
+{
+    return make_float4(clip1(b.x, image_w), clip1(b.y, image_h), clip1(b.z, image_w),
+                       clip1(b.w, image_h));
+}
+
+#define FRCNN_DW_CLAMP 4.135166556742356 /* math.log(1000. / 16), utils.py:193 */
+
+__global__ void __launch_bounds__(256) box_regression_kernel(const float4 *__restrict__ box,
+                                                             const float4 *__restrict__ regs,
+                                                             int n, int K,
+                                                             float4 *__restrict__ out)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * K) return;
+    int row = (int)(i / K);
+    out[i] = decode_one(box[row], regs[i], (float)FRCNN_DW_CLAMP);
+}
+
+extern "C" int frcnn_box_regression_f32(const float *box, const float *regs, int n, int K,
+                                        float *out, void *stream)
+{
+    FRCNN_REQUIRE(n >= 0 && K > 0, "box_regression: bad shape");
+    if (n == 0) return FRCNN_OK;
+    FRCNN_REQUIRE(box && regs && out, "box_regression: null pointer");
+    long long total = (long long)n * K;
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(box_regression_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)box, (const float4 *)regs, n, K, (float4 *)out);
+    FRCNN_CHECK_LAUNCH("box_regression");
+    return FRCNN_OK;
+}
+
+__global__ void __launch_bounds__(256) box_clip_kernel(const float4 *__restrict__ box, int n,
+                                                       float image_h, float image_w,
+                                                       float4 *__restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = clip_box(box[i], image_h, image_w);
+}
+
+extern "C" int frcnn_box_clip_f32(const float *box, int n, float image_h, float image_w, float *out,
+                                  void *stream)
+{
+    FRCNN_REQUIRE(n >= 0, "box_clip: bad shape");
+    if (n == 0) return FRCNN_OK;
+    FRCNN_REQUIRE(box && out, "box_clip: null pointer");
+    hipLaunchKernelGGL(box_clip_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)box, n, image_h, image_w, (float4 *)out);
+    FRCNN_CHECK_LAUNCH("box_clip");
+    return FRCNN_OK;
+}
+
+// Order-preserving compaction by one 1024-thread block that sweeps the rows in tiles.
+// MODE 0: keep boxes with w > t && h > t (writes box_out + index); MODE 1: keep value > t.
+template <int MODE>
+__global__ void __launch_bounds__(1024) compact_kernel(const float4 *__restrict__ box,
+                                                       const float *__restrict__ value, int n,
+                                                       float thresh, float4 *__restrict__ box_out,
+                                                       int64_t *__restrict__ index_out,
+                                                       int32_t *__restrict__ count_out)
+{
+    __shared__ int wave_sums[16];
+    int base = 0;
+    for (int start = 0; start < n; start += 1024) {
+        int i = start + threadIdx.x;
+        bool keep = false;
+        float4 b = make_float4(0, 0, 0, 0);
+        if (i < n) {
+            if (MODE == 0) {
+                b = box[i];
+                float w = b.z - b.x;
+                float h = b.w - b.y;
+                keep = (w > thresh) && (h > thresh);
+            } else {
+                keep = value[i] > thresh;
+            }
+        }
+        int tot;
+        int pos = base + frcnn_block_excl_count(keep, wave_sums, &tot);
+        if (keep) {
+            if (MODE == 0) box_out[pos] = b;
+            index_out[pos] = i;
+        }
+        base += tot;
+    }
+    if (threadIdx.x == 0) *count_out = base;
+}
+
+extern "C" int frcnn_remove_small_box_f32(const float *box, int n, float size_thresh,
+                                          float *box_out, int64_t *index_out, int32_t *count_out,
+                                          void *stream)
+{
+    FRCNN_REQUIRE(n >= 0 && count_out, "remove_small_box: bad arguments");
+    FRCNN_REQUIRE(n == 0 || (box && box_out && index_out), "remove_small_box: null pointer");
+    hipLaunchKernelGGL(compact_kernel<0>, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                       (const float4 *)box, (const float *)nullptr, n, size_thresh,
+                       (float4 *)box_out, index_out, count_out);
+    FRCNN_CHECK_LAUNCH("remove_small_box");
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_select_gt_f32(const float *value, int n, float thresh, int64_t *index_out,
+                                   int32_t *count_out, void *stream)
+{
+    FRCNN_REQUIRE(n >= 0 && count_out, "select_gt: bad arguments");
+    FRCNN_REQUIRE(n == 0 || (value && index_out), "select_gt: null pointer");
+    hipLaunchKernelGGL(compact_kernel<1>, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                       (const float4 *)nullptr, value, n, thresh, (float4 *)nullptr, index_out,
+                       count_out);
+    FRCNN_CHECK_LAUNCH("select_gt");
+    return FRCNN_OK;
+}
+
+// Fused gather + decode + clip + small-box compaction: one 1024-thread block per image.
+__global__ void __launch_bounds__(1024)
+decode_clip_filter_kernel(const float4 *__restrict__ anchors, long long anchor_batch_stride4,
+                          const float4 *__restrict__ deltas, const int32_t *__restrict__ top_idx,
+                          const float *__restrict__ top_score, int A, int k, float image_h,
+                          float image_w, float min_size, float4 *__restrict__ boxes_out,
+                          float *__restrict__ scores_out, int32_t *__restrict__ src_out,
+                          int32_t *__restrict__ count_out)
+{
+    __shared__ int wave_sums[16];
+    const int b = blockIdx.x;
+    const float4 *anc = anchors + (long long)b * anchor_batch_stride4;
+    const float4 *del = deltas + (long long)b * A;
+    const int32_t *idx = top_idx + (long long)b * k;
+    const float *sc = top_score + (long long)b * k;
+    float4 *bo = boxes_out + (long long)b * k;
+    float *so = scores_out + (long long)b * k;
+    int32_t *ro = src_out + (long long)b * k;
+    int base = 0;
+    for (int start = 0; start < k; start += 1024) {
+        int i = start + threadIdx.x;
+        bool keep = false;
+        float4 p = make_float4(0, 0, 0, 0);
+        float s = 0.0f;
+        if (i < k) {
+            int a = idx[i];
+            s = sc[i];
+            p = decode_one(anc[a], del[a], (float)FRCNN_DW_CLAMP);
+            p = clip_box(p, image_h, image_w);
+            float w = p.z - p.x;
+            float h = p.w - p.y;
+            keep = (w > min_size) && (h > min_size);
+        }
+        int tot;
+        int pos = base + frcnn_block_excl_count(keep, wave_sums, &tot);
+        if (keep) {
+            bo[pos] = p;
+            so[pos] = s;
+            ro[pos] = i;
+        }
+        base += tot;
+    }
+    if (threadIdx.x == 0) count_out[b] = base;
+}
+
+extern "C" int frcnn_decode_clip_filter_f32(const float *anchors, int64_t anchor_batch_stride,
+                                            const float *deltas, const int32_t *top_idx,
+                                            const float *top_score, int B, int A, int k,
+                                            float image_h, float image_w, float min_size,
+                                            float *boxes_out, float *scores_out, int32_t *src_out,
+                                            int32_t *count_out, void *stream)
+{
+    FRCNN_REQUIRE(B > 0 && A > 0 && k > 0 && k <= A, "decode_clip_filter: bad shape");
+    FRCNN_REQUIRE(anchors && deltas && top_idx && top_score && boxes_out && scores_out && src_out &&
+                      count_out,
+                  "decode_clip_filter: null pointer");
+    FRCNN_REQUIRE(anchor_batch_stride % 4 == 0, "decode_clip_filter: anchor stride not a box multiple");
+    hipLaunchKernelGGL(decode_clip_filter_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream,
+                       (const float4 *)anchors, (long long)(anchor_batch_stride / 4),
+                       (const float4 *)deltas, top_idx, top_score, A, k, image_h, image_w, min_size,
+                       (float4 *)boxes_out, scores_out, src_out, count_out);
+    FRCNN_CHECK_LAUNCH("decode_clip_filter");
+    return FRCNN_OK;
+}
+
+// ---- gather -----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_boxes_kernel(const float4 *__restrict__ src,
+                                                           const int32_t *__restrict__ idx,
+                                                           const int32_t *__restrict__ count, int n,
+                                                           int m, float4 *__restrict__ out)
+{
+    int b = blockIdx.y;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    int c = count ? count[b] : m;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (j < c) {
+        int s = idx[(long long)b * m + j];
+        if (s >= 0 && s < n) v = src[(long long)b * n + s];
+    }
+    out[(long long)b * m + j] = v;
+}
+
+extern "C" int frcnn_gather_boxes_f32(const float *src, const int32_t *idx, const int32_t *count,
+                                      int B, int n, int m, float *out, void *stream)
+{
+    FRCNN_REQUIRE(B >= 0 && n >= 0 && m >= 0, "gather_boxes: bad shape");
+    if (B == 0 || m == 0) return FRCNN_OK;
+    FRCNN_REQUIRE(idx && out && (n == 0 || src), "gather_boxes: null pointer");
+    hipLaunchKernelGGL(gather_boxes_kernel, dim3((m + 255) / 256, B), dim3(256), 0,
+                       (hipStream_t)stream, (const float4 *)src, idx, count, n, m, (float4 *)out);
+    FRCNN_CHECK_LAUNCH("gather_boxes");
+    return FRCNN_OK;
+}
+
+// ---- K5 IoU matrix + fused label/encode -------------------------------------------------------
+#define IOU_TILE_M 256
+
+// (n, m) materialised IoU: a block owns 256 rows (one per lane) and sweeps box_2 in LDS tiles of
+// 256; each lane writes its row segment.  Only used for API parity with utils.box_iou.
+__global__ void __launch_bounds__(256) box_iou_kernel(const float4 *__restrict__ box1, int n,
+                                                      const float4 *__restrict__ box2, int m,
+                                                      float *__restrict__ out)
+{
+    __shared__ float4 s_box[IOU_TILE_M];
+    __shared__ float s_area[IOU_TILE_M];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 a = make_float4(0, 0, 0, 0);
+    if (i < n) a = box1[i];
+    float aarea = frcnn_area(a.x, a.y, a.z, a.w);
+    for (int j0 = 0; j0 < m; j0 += IOU_TILE_M) {
+        int jn = min(IOU_TILE_M, m - j0);
+        __syncthreads();
+        if ((int)threadIdx.x < jn) {
+            float4 g = box2[j0 + threadIdx.x];
+            s_box[threadIdx.x] = g;
+            s_area[threadIdx.x] = frcnn_area(g.x, g.y, g.z, g.w);
+        }
+        __syncthreads();
+        if (i < n) {
+            float *o = out + (long long)i * m + j0;
+            for (int j = 0; j < jn; ++j) {
+                float4 g = s_box[j];
+                o[j] = frcnn_iou(a.x, a.y, a.z, a.w, aarea, g.x, g.y, g.z, g.w, s_area[j]);
+            }
+        }
+    }
+}
+
+extern "C" int frcnn_box_iou_f32(const float *box1, int n, const float *box2, int m, float *out,
+                                 void *stream)
+{
+    FRCNN_REQUIRE(n >= 0 && m >= 0, "box_iou: bad shape");
+    if (n == 0 || m == 0) return FRCNN_OK;
+    FRCNN_REQUIRE(box1 && box2 && out, "box_iou: null pointer");
+    hipLaunchKernelGGL(box_iou_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)box1, n, (const float4 *)box2, m, out);
+    FRCNN_CHECK_LAUNCH("box_iou");
+    return FRCNN_OK;
+}
+
+struct Weights4 {
+    float x, y, w, h;
+};
+
+// One lane per box_1 row; the image's ground-truth boxes (+ areas) are staged in LDS tiles and
+// swept by every lane (wave-uniform LDS address => broadcast reads).  Running max follows
+// torch.max(dim=1): replace when !(v <= best); the first NaN wins and freezes the row.
+__global__ void __launch_bounds__(256)
+iou_label_encode_kernel(const float4 *__restrict__ box1, long long box1_batch_stride4,
+                        const float4 *__restrict__ box2, const int32_t *__restrict__ m_per_image,
+                        const float *__restrict__ labels, int N, int m_max, float neg_thr,
+                        float pos_thr, Weights4 wt, float *__restrict__ label_out,
+                        int32_t *__restrict__ argmax_out, float *__restrict__ max_iou_out,
+                        float4 *__restrict__ dev_out)
+{
+    __shared__ float4 s_box[IOU_TILE_M];
+    __shared__ float s_area[IOU_TILE_M];
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = m_per_image ? m_per_image[b] : m_max;
+    const float4 *gt = box2 + (long long)b * m_max;
+    float4 a = make_float4(0, 0, 0, 0);
+    if (i < N) a = box1[(long long)b * box1_batch_stride4 + i];
+    float aarea = frcnn_area(a.x, a.y, a.z, a.w);
+    float best = 0.0f;
+    int arg = 0;
+    bool frozen = false;
+    for (int j0 = 0; j0 < m; j0 += IOU_TILE_M) {
+        int jn = min(IOU_TILE_M, m - j0);
+        __syncthreads();
+        if ((int)threadIdx.x < jn) {
+            float4 g = gt[j0 + threadIdx.x];
+            s_box[threadIdx.x] = g;
+            s_area[threadIdx.x] = frcnn_area(g.x, g.y, g.z, g.w);
+        }
+        __syncthreads();
+        for (int j = 0; j < jn; ++j) {
+            float4 g = s_box[j];
+            float v = frcnn_iou(a.x, a.y, a.z, a.w, aarea, g.x, g.y, g.z, g.w, s_area[j]);
+            bool first = (j0 + j) == 0;
+            bool take = !frozen && (first || !(v <= best));
+            if (take) {
+                best = v;
+                arg = j0 + j;
+                frozen = (v != v);
+            }
+        }
+    }
+    if (i >= N) return;
+    long long o = (long long)b * N + i;
+    if (max_iou_out) max_iou_out[o] = best;
+    if (argmax_out) argmax_out[o] = arg;
+    if (label_out) {
+        // utils.py:275-290: zeros; pos -> 1 / labels[arg]; then neg -> 0; then mid -> -1
+        float lab = 0.0f;
+        if (best > pos_thr) lab = labels ? labels[(long long)b * m_max + arg] : 1.0f;
+        if (best < neg_thr) lab = 0.0f;
+        if (best >= neg_thr && best <= pos_thr) lab = -1.0f;
+        label_out[o] = lab;
+    }
+    if (dev_out) {
+        // utils.py:147-161 on the argmax ground truth only (the reference builds all (N,M,4))
+        float4 g = gt[arg];
+        float w1 = a.z - a.x, h1 = a.w - a.y;
+        float cx1 = a.x + w1 / 2.0f, cy1 = a.y + h1 / 2.0f;
+        float w2 = g.z - g.x, h2 = g.w - g.y;
+        float cx2 = g.x + w2 / 2.0f, cy2 = g.y + h2 / 2.0f;
+        dev_out[o] = make_float4(wt.x * ((cx2 - cx1) / w1), wt.y * ((cy2 - cy1) / h1),
+                                 wt.w * logf(w2 / w1), wt.h * logf(h2 / h1));
+    }
+}
+
+extern "C" int frcnn_iou_label_encode_f32(const float *box1, int64_t box1_batch_stride,
+                                          const float *box2, const int32_t *m_per_image,
+                                          const float *labels, int B, int N, int m_max,
+                                          float neg_threshold, float pos_threshold,
+                                          const float *weights_host, float *label_out,
+                                          int32_t *argmax_out, float *max_iou_out, float *dev_out,
+                                          void *stream)
+{
+    FRCNN_REQUIRE(B > 0 && N >= 0 && m_max > 0, "iou_label_encode: bad shape (every image needs >= 1 box_2 row)");
+    if (N == 0) return FRCNN_OK;
+    FRCNN_REQUIRE(box1 && box2, "iou_label_encode: null pointer");
+    FRCNN_REQUIRE(box1_batch_stride % 4 == 0, "iou_label_encode: box1 stride not a box multiple");
+    Weights4 wt = {1.0f, 1.0f, 1.0f, 1.0f};
+    if (weights_host) wt = {weights_host[0], weights_host[1], weights_host[2], weights_host[3]};
+    hipLaunchKernelGGL(iou_label_encode_kernel, dim3((N + 255) / 256, B), dim3(256), 0,
+                       (hipStream_t)stream, (const float4 *)box1,
+                       (long long)(box1_batch_stride / 4), (const float4 *)box2, m_per_image, labels,
+                       N, m_max, neg_threshold, pos_threshold, wt, label_out, argmax_out,
+                       max_iou_out, (float4 *)dev_out);
+    FRCNN_CHECK_LAUNCH("iou_label_encode");
+    return FRCNN_OK;
+}

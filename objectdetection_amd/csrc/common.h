@@ -1,0 +1,89 @@
+// common.h -- shared helpers for the gfx950 kernels of libfrcnn_hip.so.
+// Built with -ffp-contract=off: every fp32 mul/add/sub/div below rounds separately, which is
+// what bit-exact parity with the reference's torch ops needs (hard part 1).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/frcnn_hip.h"
+
+#define FRCNN_WAVE 64
+
+void frcnn_set_error(const char *fmt, ...);
+
+#define FRCNN_REQUIRE(cond, ...)                                                                    \
+    do {                                                                                            \
+        if (!(cond)) {                                                                              \
+            frcnn_set_error(__VA_ARGS__);                                                           \
+            return FRCNN_EINVAL;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+// Called after every launch: reports a bad launch configuration without synchronising.
+#define FRCNN_CHECK_LAUNCH(name)                                                                    \
+    do {                                                                                            \
+        hipError_t e_ = hipGetLastError();                                                          \
+        if (e_ != hipSuccess) {                                                                     \
+            frcnn_set_error("%s: %s", name, hipGetErrorString(e_));                                 \
+            return FRCNN_ELAUNCH;                                                                   \
+        }                                                                                           \
+    } while (0)
+
+static inline size_t frcnn_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- device helpers -------------------------------------------------------------------------
+
+__device__ __forceinline__ float frcnn_area(float x1, float y1, float x2, float y2)
+{
+    float w = x2 - x1;
+    float h = y2 - y1;
+    return w * h;
+}
+
+// utils.py:114-119 / torchvision nms: inter / ((area_a + area_b) - inter), 0/0 -> NaN.
+__device__ __forceinline__ float frcnn_iou(float ax1, float ay1, float ax2, float ay2, float aarea,
+                                           float bx1, float by1, float bx2, float by2, float barea)
+{
+    float ltx = ax1 > bx1 ? ax1 : bx1;
+    float lty = ay1 > by1 ? ay1 : by1;
+    float rbx = ax2 < bx2 ? ax2 : bx2;
+    float rby = ay2 < by2 ? ay2 : by2;
+    float jw = rbx - ltx;
+    float jh = rby - lty;
+    jw = jw < 0.0f ? 0.0f : jw;
+    jh = jh < 0.0f ? 0.0f : jh;
+    float inter = jw * jh;
+    return inter / ((aarea + barea) - inter);
+}
+
+// Order-preserving unsigned key of an fp32 score: larger key = ranks first.
+// NaN -> 0xFFFFFFFF (above +inf, as torch.topk treats NaN), -0.0 below +0.0.
+__device__ __forceinline__ uint32_t frcnn_score_key(float s)
+{
+    uint32_t u = __float_as_uint(s);
+    if (s != s) return 0xFFFFFFFFu;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Exclusive prefix count of `flag` over a 1024-thread (16-wave) block; returns the block total
+// through *total.  `wave_sums` is 16 ints of LDS.  Two barriers.
+__device__ __forceinline__ int frcnn_block_excl_count(bool flag, int *wave_sums, int *total)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwave = blockDim.x >> 6;
+    unsigned long long m = __ballot(flag);
+    int in_wave = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_sums[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nwave; ++w) {
+        int s = wave_sums[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + in_wave;
+}

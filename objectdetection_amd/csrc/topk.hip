@@ -1,0 +1,276 @@
+// topk.hip -- K2: RPN output flattening and per-image sorted top-k.
+//
+// Replaces RPN/rpn.py:56-57 (permute/flatten/cat) and RPN/rpn.py:65-66 (torch.topk per image).
+//
+// Top-k = radix SELECT of the k-th largest key (4 x 8-bit MSB-first histogram passes over the
+// image's scores, LDS histograms, wave-aggregated LDS atomics), an index-ordered compaction of
+// the k winners, then a stable 4-pass LSD radix SORT of the winners (wave-private digit counters
+// in LDS, 64-wide ballot "match" ranking, ping-pong buffers that stay L2-resident).  One
+// 1024-thread workgroup (16 wave64) owns one image; the batch is the grid.  Everything is
+// integer/key work: the result is bit-exact by construction and the ordering rule is
+// "descending key, ties by ascending index" (the stable sort of an index-ordered list).
+#include "common.h"
+
+// ---- flatten ----------------------------------------------------------------------------------
+// cls (B,na,h,w) -> scores[b, off + cell*na + a]; reg (B,4na,h,w) -> deltas[b, off + cell*na + a].
+// A block handles 64 cells: NCHW reads are coalesced along the cell index (x fastest), the
+// transposed writes go through LDS so that they are coalesced along (cell, a).
+#define FLAT_CELLS 64
+
+__global__ void __launch_bounds__(256)
+rpn_flatten_kernel(const float *__restrict__ cls, const float *__restrict__ reg, int na, int hw,
+                   int level_offset, int A_total, float *__restrict__ scores,
+                   float4 *__restrict__ deltas)
+{
+    extern __shared__ float s_tile[]; // [5*na][FLAT_CELLS + 1]: rows 0..na-1 cls, then 4*na reg
+    const int b = blockIdx.y;
+    const int cell0 = blockIdx.x * FLAT_CELLS;
+    const int ncell = min(FLAT_CELLS, hw - cell0);
+    const int rows = 5 * na;
+    const float *cls_b = cls + (long long)b * na * hw;
+    const float *reg_b = reg + (long long)b * 4 * na * hw;
+    for (int t = threadIdx.x; t < rows * FLAT_CELLS; t += blockDim.x) {
+        int r = t / FLAT_CELLS;
+        int c = t - r * FLAT_CELLS;
+        if (c < ncell) {
+            float v = r < na ? cls_b[(long long)r * hw + cell0 + c]
+                             : reg_b[(long long)(r - na) * hw + cell0 + c];
+            s_tile[r * (FLAT_CELLS + 1) + c] = v;
+        }
+    }
+    __syncthreads();
+    const long long out0 = (long long)b * A_total + level_offset + (long long)cell0 * na;
+    for (int t = threadIdx.x; t < ncell * na; t += blockDim.x) {
+        int c = t / na;
+        int a = t - c * na;
+        scores[out0 + t] = s_tile[a * (FLAT_CELLS + 1) + c];
+        float4 d;
+        d.x = s_tile[(na + 4 * a + 0) * (FLAT_CELLS + 1) + c];
+        d.y = s_tile[(na + 4 * a + 1) * (FLAT_CELLS + 1) + c];
+        d.z = s_tile[(na + 4 * a + 2) * (FLAT_CELLS + 1) + c];
+        d.w = s_tile[(na + 4 * a + 3) * (FLAT_CELLS + 1) + c];
+        deltas[out0 + t] = d;
+    }
+}
+
+extern "C" int frcnn_rpn_flatten_f32(const float *cls, const float *reg, int B, int na, int h, int w,
+                                     int level_offset, int A_total, float *scores, float *deltas,
+                                     void *stream)
+{
+    FRCNN_REQUIRE(B > 0 && na > 0 && h > 0 && w > 0, "rpn_flatten: bad shape");
+    FRCNN_REQUIRE(cls && reg && scores && deltas, "rpn_flatten: null pointer");
+    long long hw = (long long)h * w;
+    FRCNN_REQUIRE(level_offset >= 0 && level_offset + hw * na <= A_total,
+                  "rpn_flatten: level does not fit in A_total");
+    size_t lds = (size_t)5 * na * (FLAT_CELLS + 1) * sizeof(float);
+    FRCNN_REQUIRE(lds <= 64 * 1024, "rpn_flatten: too many anchors per cell (%d)", na);
+    int blocks = (int)((hw + FLAT_CELLS - 1) / FLAT_CELLS);
+    hipLaunchKernelGGL(rpn_flatten_kernel, dim3(blocks, B), dim3(256), lds, (hipStream_t)stream, cls,
+                       reg, na, (int)hw, level_offset, A_total, scores, (float4 *)deltas);
+    FRCNN_CHECK_LAUNCH("rpn_flatten");
+    return FRCNN_OK;
+}
+
+// ---- top-k ------------------------------------------------------------------------------------
+#define TOPK_THREADS 1024
+#define TOPK_WAVES 16
+
+// Adds 1 to hist[digit] for every active lane with one LDS atomic per distinct digit in the wave.
+__device__ __forceinline__ void wave_hist_add(unsigned *hist, unsigned digit, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        unsigned d = __shfl(digit, leader);
+        unsigned long long same = __ballot(active && digit == d) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ val_out,
+            int32_t *__restrict__ idx_out, uint32_t *__restrict__ ws)
+{
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_cnt[TOPK_WAVES][256];
+    __shared__ unsigned s_digit_base[256];
+    __shared__ int s_wave_sums[16];
+    __shared__ unsigned s_prefix, s_remaining;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float *sc = scores + (long long)b * n;
+    uint32_t *keyA = ws + (long long)b * 4 * k;
+    uint32_t *idxA = keyA + k;
+    uint32_t *keyB = idxA + k;
+    uint32_t *idxB = keyB + k;
+
+    // ---- 1. radix select: key of the k-th largest element, and how many of its equals to take
+    unsigned prefix = 0, mask = 0, remaining = (unsigned)k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+            int i = i0 + tid;
+            bool act = false;
+            unsigned dg = 0;
+            if (i < n) {
+                unsigned key = frcnn_score_key(sc[i]);
+                act = (key & mask) == prefix;
+                dg = (key >> shift) & 255u;
+            }
+            wave_hist_add(s_hist, dg, act);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                unsigned h = s_hist[d];
+                if (cum + h >= remaining) break;
+                cum += h;
+            }
+            s_prefix = prefix | ((unsigned)d << shift);
+            s_remaining = remaining - cum;
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        remaining = s_remaining;
+        mask |= 255u << shift;
+    }
+    const unsigned T = prefix;        // key of the k-th largest
+    const unsigned need_eq = remaining; // how many elements with key == T are selected (lowest idx)
+
+    // ---- 2. index-ordered compaction of the k winners into (keyA, idxA)
+    {
+        int base = 0, eq_base = 0;
+        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+            int i = i0 + tid;
+            unsigned key = 0;
+            bool gt = false, eq = false;
+            if (i < n) {
+                key = frcnn_score_key(sc[i]);
+                gt = key > T;
+                eq = key == T;
+            }
+            int eq_tot;
+            int eq_rank = eq_base + frcnn_block_excl_count(eq, s_wave_sums, &eq_tot);
+            bool sel = gt || (eq && (unsigned)eq_rank < need_eq);
+            int tot;
+            int pos = base + frcnn_block_excl_count(sel, s_wave_sums, &tot);
+            if (sel) {
+                keyA[pos] = key;
+                idxA[pos] = (uint32_t)i;
+            }
+            base += tot;
+            eq_base += eq_tot;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. stable LSD radix sort, descending key (digit' = 255 - digit), 4 x 8 bits
+    const int seg = ((k + TOPK_WAVES - 1) / TOPK_WAVES + 63) / 64 * 64; // per-wave contiguous segment
+    const int seg_lo = min(wave * seg, k);
+    const int seg_hi = min(seg_lo + seg, k);
+    uint32_t *kin = keyA, *iin = idxA, *kout = keyB, *iout = idxB;
+    for (int shift = 0; shift < 32; shift += 8) {
+        for (int t = tid; t < TOPK_WAVES * 256; t += TOPK_THREADS) (&s_cnt[0][0])[t] = 0;
+        __syncthreads();
+        for (int e0 = seg_lo; e0 < seg_hi; e0 += 64) {
+            int e = e0 + lane;
+            bool act = e < seg_hi;
+            unsigned dg = act ? 255u - ((kin[e] >> shift) & 255u) : 0u;
+            wave_hist_add(s_cnt[wave], dg, act);
+        }
+        __syncthreads();
+        // per digit: exclusive prefix over waves, digit totals -> s_hist
+        if (tid < 256) {
+            unsigned run = 0;
+            for (int w = 0; w < TOPK_WAVES; ++w) {
+                unsigned c = s_cnt[w][tid];
+                s_cnt[w][tid] = run;
+                run += c;
+            }
+            s_hist[tid] = run;
+        }
+        __syncthreads();
+        if (wave == 0) { // exclusive scan of the 256 digit totals: 4 digits per lane + wave scan
+            unsigned v0 = s_hist[4 * lane], v1 = s_hist[4 * lane + 1], v2 = s_hist[4 * lane + 2],
+                     v3 = s_hist[4 * lane + 3];
+            unsigned sum = v0 + v1 + v2 + v3;
+            unsigned incl = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            unsigned excl = incl - sum;
+            s_digit_base[4 * lane] = excl;
+            s_digit_base[4 * lane + 1] = excl + v0;
+            s_digit_base[4 * lane + 2] = excl + v0 + v1;
+            s_digit_base[4 * lane + 3] = excl + v0 + v1 + v2;
+        }
+        __syncthreads();
+        for (int e0 = seg_lo; e0 < seg_hi; e0 += 64) {
+            int e = e0 + lane;
+            bool act = e < seg_hi;
+            unsigned key = act ? kin[e] : 0u;
+            unsigned idx = act ? iin[e] : 0u;
+            unsigned dg = 255u - ((key >> shift) & 255u);
+            unsigned long long peers = __ballot(act);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                bool one = (dg >> bit) & 1u;
+                unsigned long long bm = __ballot(one);
+                peers &= one ? bm : ~bm;
+            }
+            if (act) {
+                // wave-private row: all lanes read the running offset of their digit, then the
+                // first peer advances it (volatile: the next round must re-read it)
+                volatile unsigned *wcnt = s_cnt[wave];
+                unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+                unsigned off = wcnt[dg];
+                unsigned pos = s_digit_base[dg] + off + rank;
+                kout[pos] = key;
+                iout[pos] = idx;
+                if (rank == 0) wcnt[dg] = off + (unsigned)__popcll(peers);
+            }
+        }
+        __syncthreads();
+        uint32_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *ti = iin; iin = iout; iout = ti;
+    }
+    // 4 passes: the sorted list is back in (keyA, idxA) == (kin, iin)
+    for (int j = tid; j < k; j += TOPK_THREADS) {
+        unsigned idx = iin[j];
+        idx_out[(long long)b * k + j] = (int32_t)idx;
+        if (val_out) val_out[(long long)b * k + j] = sc[idx];
+    }
+}
+
+extern "C" size_t frcnn_topk_workspace_bytes(int B, int n, int k)
+{
+    (void)n;
+    if (B <= 0 || k <= 0) return 0;
+    return (size_t)B * 4 * (size_t)k * sizeof(uint32_t);
+}
+
+extern "C" int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, float *val_out,
+                                   int32_t *idx_out, void *workspace, size_t workspace_bytes,
+                                   void *stream)
+{
+    FRCNN_REQUIRE(B >= 0 && n >= 0 && k >= 0 && k <= n, "topk: bad shape (B=%d n=%d k=%d)", B, n, k);
+    if (B == 0 || k == 0) return FRCNN_OK;
+    FRCNN_REQUIRE(scores && idx_out && workspace, "topk: null pointer");
+    if (workspace_bytes < frcnn_topk_workspace_bytes(B, n, k)) {
+        frcnn_set_error("topk: workspace too small (%zu < %zu)", workspace_bytes,
+                        frcnn_topk_workspace_bytes(B, n, k));
+        return FRCNN_EWORKSPACE;
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream, scores, n,
+                       k, val_out, idx_out, (uint32_t *)workspace);
+    FRCNN_CHECK_LAUNCH("topk");
+    return FRCNN_OK;
+}

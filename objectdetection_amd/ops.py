@@ -1,0 +1,442 @@
+"""Torch-facing wrappers over the C ABI (include/frcnn_hip.h).
+
+torch is used for device memory and streams only: every wrapper allocates its outputs with
+torch.empty on the inputs' device, hands raw device pointers plus the current HIP stream to
+libfrcnn_hip.so, and returns without synchronising.  Batched entry points take a leading image
+dimension so that a whole batch is one launch (the reference loops over images in Python:
+RPN/rpn.py:63,74,80,105; ROIHead/roi_head.py:99,178).
+
+Also exports `nms` and `MultiScaleRoIAlign` with torchvision's signatures, because the reference
+imports those two names (RPN/rpn.py:18, ROIHead/roi_head.py:26, ROIHead/roi_pooling.py:18).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.FrcnnError(
+                "objectdetection_amd kernels run on a HIP device only (got a %s tensor); "
+                "there is no CPU fallback" % t.device)
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.detach().contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _host_f32(values):
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float32))
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+# --------------------------------------------------------------------------------- K1 anchors
+def base_anchors(sizes, ratios):
+    """(size, ratio) per base anchor -> (na,4) CPU fp32 tensor (anchor_generator.py:43-64)."""
+    s, sp = _host_f32(sizes)
+    r, rp = _host_f32(ratios)
+    out = np.empty((len(s), 4), np.float32)
+    rc = _lib.load().frcnn_base_anchors_f32(sp, rp, len(s), out.ctypes.data_as(ctypes.c_void_p))
+    _lib.check(rc, "base_anchors")
+    return torch.from_numpy(out)
+
+
+def anchor_grid(base, fh, fw, stride_y, stride_x):
+    """One level of generate_anchor -> (fh*fw, na, 4) (anchor_generator.py:66-95)."""
+    _need_gpu(base)
+    base = _f32c(base)
+    na = base.shape[0]
+    out = torch.empty((fh * fw, na, 4), dtype=torch.float32, device=base.device)
+    with torch.cuda.device(base.device):
+        rc = _lib.load().frcnn_anchor_grid_f32(_ptr(base), na, fh, fw, float(stride_y), float(stride_x),
+                                               _ptr(out), _stream())
+    _lib.check(rc, "anchor_grid")
+    return out
+
+
+# --------------------------------------------------------------------------- K2 flatten, top-k
+def rpn_flatten(list_cls, list_regs):
+    """RPN/rpn.py:56-57: -> scores (B, A), deltas (B, A, 4); flat index = level_off + cell*na + a."""
+    _need_gpu(*list_cls, *list_regs)
+    B = list_cls[0].shape[0]
+    na = list_cls[0].shape[1]
+    sizes = [c.shape[2] * c.shape[3] * c.shape[1] for c in list_cls]
+    A = sum(sizes)
+    dev = list_cls[0].device
+    scores = torch.empty((B, A), dtype=torch.float32, device=dev)
+    deltas = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    off = 0
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        for cls, reg, sz in zip(list_cls, list_regs, sizes):
+            if cls.shape[1] != na or reg.shape[1] != 4 * na or reg.shape[2:] != cls.shape[2:]:
+                raise ValueError("rpn head outputs disagree: cls %s reg %s" % (tuple(cls.shape), tuple(reg.shape)))
+            cls_c, reg_c = _f32c(cls), _f32c(reg)
+            rc = lib.frcnn_rpn_flatten_f32(_ptr(cls_c), _ptr(reg_c), B, na, cls.shape[2], cls.shape[3], off, A,
+                                           _ptr(scores), _ptr(deltas), _stream())
+            _lib.check(rc, "rpn_flatten")
+            off += sz
+    return scores, deltas
+
+
+def topk_desc(scores, k, want_values=True):
+    """Per-row sorted top-k (RPN/rpn.py:65-66).  scores (B,n) -> values (B,k), indices (B,k) int32."""
+    _need_gpu(scores)
+    scores = _f32c(scores)
+    B, n = scores.shape
+    if k > n:
+        raise ValueError("k (%d) > n (%d)" % (k, n))
+    dev = scores.device
+    vals = torch.empty((B, k), dtype=torch.float32, device=dev) if want_values else None
+    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.frcnn_topk_workspace_bytes(B, n, k)
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.frcnn_topk_desc_f32(_ptr(scores), B, n, k, _ptr(vals), _ptr(idx), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "topk_desc")
+    return vals, idx
+
+
+# ------------------------------------------------------------------ K3 decode / clip / filter
+def box_regression(box, regs):
+    _need_gpu(box, regs)
+    box, regs = _f32c(box), _f32c(regs)
+    n = box.shape[0]
+    if box.dim() != 2 or box.shape[1] != 4 or regs.dim() != 2 or regs.shape[0] != n or regs.shape[1] % 4:
+        raise ValueError("box_regression expects box (n,4) and regression_params (n,4K); got %s, %s"
+                         % (tuple(box.shape), tuple(regs.shape)))
+    K = regs.shape[1] // 4
+    out = torch.empty_like(regs)
+    with torch.cuda.device(box.device):
+        rc = _lib.load().frcnn_box_regression_f32(_ptr(box), _ptr(regs), n, K, _ptr(out), _stream())
+    _lib.check(rc, "box_regression")
+    return out
+
+
+def box_clip(box, image_h, image_w):
+    _need_gpu(box)
+    box = _f32c(box)
+    if box.dim() != 2 or box.shape[1] != 4:
+        raise ValueError("box_clip expects (n,4); got %s" % (tuple(box.shape),))
+    out = torch.empty_like(box)
+    with torch.cuda.device(box.device):
+        rc = _lib.load().frcnn_box_clip_f32(_ptr(box), box.shape[0], float(image_h), float(image_w), _ptr(out),
+                                            _stream())
+    _lib.check(rc, "box_clip")
+    return out
+
+
+def remove_small_box(box, size_thresh):
+    """-> (box_out (n,4) [first count rows valid], index (n) int64, count (1) int32 device)."""
+    _need_gpu(box)
+    box = _f32c(box)
+    n = box.shape[0]
+    dev = box.device
+    box_out = torch.empty_like(box)
+    index = torch.empty((n,), dtype=torch.int64, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().frcnn_remove_small_box_f32(_ptr(box), n, float(size_thresh), _ptr(box_out), _ptr(index),
+                                                    _ptr(count), _stream())
+    _lib.check(rc, "remove_small_box")
+    return box_out, index, count
+
+
+def select_gt(value, thresh):
+    """index = where(value > thresh)[0] -> (index (n) int64, count (1) int32 device)."""
+    _need_gpu(value)
+    value = _f32c(value).reshape(-1)
+    n = value.shape[0]
+    index = torch.empty((n,), dtype=torch.int64, device=value.device)
+    count = torch.empty((1,), dtype=torch.int32, device=value.device)
+    with torch.cuda.device(value.device):
+        rc = _lib.load().frcnn_select_gt_f32(_ptr(value), n, float(thresh), _ptr(index), _ptr(count), _stream())
+    _lib.check(rc, "select_gt")
+    return index, count
+
+
+def decode_clip_filter(anchors, deltas, top_idx, top_score, image_h, image_w, min_size):
+    """Fused RPN/rpn.py:67-83 for a batch.  anchors (A,4) shared or (B,A,4); deltas (B,A,4);
+    top_idx / top_score (B,k).  -> boxes (B,k,4), scores (B,k), src (B,k) int32, count (B) int32."""
+    _need_gpu(anchors, deltas, top_idx, top_score)
+    anchors, deltas, top_score = _f32c(anchors), _f32c(deltas), _f32c(top_score)
+    top_idx = top_idx.contiguous()
+    if top_idx.dtype != torch.int32:
+        top_idx = top_idx.to(torch.int32)
+    B, A = deltas.shape[0], deltas.shape[1]
+    k = top_idx.shape[1]
+    if anchors.dim() == 2:
+        stride = 0
+        if anchors.shape[0] != A:
+            raise ValueError("anchors (%d) and deltas (%d) disagree" % (anchors.shape[0], A))
+    else:
+        stride = A * 4
+        if anchors.shape[0] != B or anchors.shape[1] != A:
+            raise ValueError("anchors %s vs deltas %s" % (tuple(anchors.shape), tuple(deltas.shape)))
+    dev = deltas.device
+    boxes = torch.empty((B, k, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, k), dtype=torch.float32, device=dev)
+    src = torch.empty((B, k), dtype=torch.int32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().frcnn_decode_clip_filter_f32(
+            _ptr(anchors), stride, _ptr(deltas), _ptr(top_idx), _ptr(top_score), B, A, k, float(image_h),
+            float(image_w), float(min_size), _ptr(boxes), _ptr(scores), _ptr(src), _ptr(count), _stream())
+    _lib.check(rc, "decode_clip_filter")
+    return boxes, scores, src, count
+
+
+# --------------------------------------------------------------------------------------- K4 NMS
+def nms_sorted(boxes, n_per_image, iou_threshold, max_keep):
+    """Batched greedy NMS over rows already in descending-score order.
+    boxes (B,n,4); n_per_image (B) int32 device or None.  -> keep (B,max_keep) int32, n_keep (B)."""
+    _need_gpu(boxes, n_per_image)
+    boxes = _f32c(boxes)
+    B, n = boxes.shape[0], boxes.shape[1]
+    dev = boxes.device
+    max_keep = int(max_keep)
+    keep = torch.empty((B, max(max_keep, 1)), dtype=torch.int32, device=dev)
+    n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.frcnn_nms_workspace_bytes(B, n)
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+    if n_per_image is not None and n_per_image.dtype != torch.int32:
+        n_per_image = n_per_image.to(torch.int32)
+    with torch.cuda.device(dev):
+        rc = lib.frcnn_nms_sorted_f32(_ptr(boxes), _ptr(n_per_image), B, n, float(iou_threshold), max_keep,
+                                      _ptr(keep), _ptr(n_keep), _ptr(ws), nbytes, _stream())
+    _lib.check(rc, "nms_sorted")
+    return keep[:, :max_keep], n_keep
+
+
+def gather_boxes(src, idx, count=None):
+    """out[b,j] = src[b, idx[b,j]] for j < count[b], zero rows after.  src (B,n,4); idx (B,m) int32."""
+    _need_gpu(src, idx, count)
+    src = _f32c(src)
+    idx = idx.contiguous()
+    B, n = src.shape[0], src.shape[1]
+    m = idx.shape[1]
+    out = torch.empty((B, m, 4), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = _lib.load().frcnn_gather_boxes_f32(_ptr(src), _ptr(idx), _ptr(count), B, n, m, _ptr(out), _stream())
+    _lib.check(rc, "gather_boxes")
+    return out
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms(boxes, scores, iou_threshold) -> int64 indices of kept boxes in
+    descending-score order (call sites RPN/rpn.py:84, ROIHead/roi_head.py:215)."""
+    _need_gpu(boxes, scores)
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    if boxes.dim() != 2 or boxes.shape[1] != 4 or scores.dim() != 1 or scores.shape[0] != n:
+        raise ValueError("nms expects boxes (n,4) and scores (n,); got %s, %s" % (tuple(boxes.shape), tuple(scores.shape)))
+    _, order = topk_desc(scores.reshape(1, n), n, want_values=False)
+    sorted_boxes = gather_boxes(boxes.reshape(1, n, 4), order)
+    keep, n_keep = nms_sorted(sorted_boxes, None, iou_threshold, n)
+    cnt = int(n_keep.item())
+    return order[0, keep[0, :cnt].long()].long()
+
+
+# ----------------------------------------------------------------------- K5 IoU, target labels
+def box_iou(box1, box2):
+    _need_gpu(box1, box2)
+    box1, box2 = _f32c(box1), _f32c(box2)
+    n, m = box1.shape[0], box2.shape[0]
+    out = torch.empty((n, m), dtype=torch.float32, device=box1.device)
+    with torch.cuda.device(box1.device):
+        rc = _lib.load().frcnn_box_iou_f32(_ptr(box1), n, _ptr(box2), m, _ptr(out), _stream())
+    _lib.check(rc, "box_iou")
+    return out
+
+
+def iou_label_encode(box1, box2, m_per_image, neg_threshold, pos_threshold, labels=None, weights=None,
+                     want=("label", "argmax", "max_iou", "dev")):
+    """Fused tagging_box + box_deviation for a batch.
+    box1 (N,4) shared or (B,N,4); box2 (B,Mmax,4); m_per_image (B) int32 device or None;
+    labels (B,Mmax) fp32 or None; weights: 4 host floats or None.
+    -> dict with the requested outputs: label (B,N), argmax (B,N) int32, max_iou (B,N), dev (B,N,4)."""
+    _need_gpu(box1, box2, m_per_image, labels)
+    box1, box2 = _f32c(box1), _f32c(box2)
+    B, m_max = box2.shape[0], box2.shape[1]
+    if m_max == 0:
+        raise ValueError("box_2 is empty: the reference's iou.max(dim=1) raises on an (N,0) matrix")
+    if box1.dim() == 2:
+        N, stride = box1.shape[0], 0
+    else:
+        N, stride = box1.shape[1], box1.shape[1] * 4
+        if box1.shape[0] != B:
+            raise ValueError("box1 batch %d vs box2 batch %d" % (box1.shape[0], B))
+    dev = box2.device
+    if labels is not None:
+        labels = _f32c(labels)
+    if m_per_image is not None and m_per_image.dtype != torch.int32:
+        m_per_image = m_per_image.to(torch.int32)
+    out = {}
+    if "label" in want:
+        out["label"] = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if "argmax" in want:
+        out["argmax"] = torch.empty((B, N), dtype=torch.int32, device=dev)
+    if "max_iou" in want:
+        out["max_iou"] = torch.empty((B, N), dtype=torch.float32, device=dev)
+    if "dev" in want:
+        out["dev"] = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    if weights is not None:
+        wa, wp = _host_f32([float(w) for w in weights])
+    else:
+        wa, wp = None, ctypes.c_void_p(0)
+    with torch.cuda.device(dev):
+        rc = _lib.load().frcnn_iou_label_encode_f32(
+            _ptr(box1), stride, _ptr(box2), _ptr(m_per_image), _ptr(labels), B, N, m_max,
+            float(np.float32(neg_threshold)), float(np.float32(pos_threshold)), wp, _ptr(out.get("label")),
+            _ptr(out.get("argmax")), _ptr(out.get("max_iou")), _ptr(out.get("dev")), _stream())
+    _lib.check(rc, "iou_label_encode")
+    return out
+
+
+# ----------------------------------------------------------------------------- K6/K7 RoI ops
+def build_rois(props, count=None):
+    """(B,P,4) padded proposals + per-image counts -> rois (B*P,5) compacted, total (1) int32 device."""
+    _need_gpu(props, count)
+    props = _f32c(props)
+    B, P = props.shape[0], props.shape[1]
+    rois = torch.empty((B * P, 5), dtype=torch.float32, device=props.device)
+    total = torch.empty((1,), dtype=torch.int32, device=props.device)
+    with torch.cuda.device(props.device):
+        rc = _lib.load().frcnn_build_rois_f32(_ptr(props), _ptr(count), B, P, _ptr(rois), _ptr(total), _stream())
+    _lib.check(rc, "build_rois")
+    return rois, total
+
+
+def level_map(rois, k_min, k_max, n_rois=None):
+    _need_gpu(rois, n_rois)
+    rois = _f32c(rois)
+    K = rois.shape[0]
+    lvl = torch.full((K,), -1, dtype=torch.int32, device=rois.device)
+    with torch.cuda.device(rois.device):
+        rc = _lib.load().frcnn_level_map_f32(_ptr(rois), _ptr(n_rois), K, int(k_min), int(k_max), _ptr(lvl), _stream())
+    _lib.check(rc, "level_map")
+    return lvl
+
+
+def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, n_rois=None, lvl=None, lvl_value=0, out=None):
+    """torchvision roi_align(aligned=False) on one level.  feat (B,C,H,W); rois (K,5) -> (K,C,ph,pw).
+    With `out` given, only rows selected by lvl == lvl_value (and < n_rois) are written."""
+    _need_gpu(feat, rois, n_rois, lvl, out)
+    feat, rois = _f32c(feat), _f32c(rois)
+    B, C, H, W = feat.shape
+    K = rois.shape[0]
+    ph, pw = int(output_size[0]), int(output_size[1])
+    if out is None:
+        # rows past *n_rois are never written; only a level-filtered call needs a zero background
+        alloc = torch.zeros if lvl is not None else torch.empty
+        out = alloc((K, C, ph, pw), dtype=torch.float32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        rc = _lib.load().frcnn_roi_align_f32(_ptr(feat), B, C, H, W, _ptr(rois), _ptr(n_rois), K, ph, pw,
+                                             float(spatial_scale), int(sampling_ratio), _ptr(lvl), int(lvl_value),
+                                             _ptr(out), _stream())
+    _lib.check(rc, "roi_align")
+    return out
+
+
+def roi_pool(feat, rois, output_size, spatial_scale):
+    """torchvision roi_pool (max) -> (out (K,C,ph,pw), argmax (K,C,ph,pw) int32)."""
+    _need_gpu(feat, rois)
+    feat, rois = _f32c(feat), _f32c(rois)
+    B, C, H, W = feat.shape
+    K = rois.shape[0]
+    ph, pw = int(output_size[0]), int(output_size[1])
+    out = torch.empty((K, C, ph, pw), dtype=torch.float32, device=feat.device)
+    arg = torch.empty((K, C, ph, pw), dtype=torch.int32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        rc = _lib.load().frcnn_roi_pool_f32(_ptr(feat), B, C, H, W, _ptr(rois), K, ph, pw, float(spatial_scale),
+                                            _ptr(out), _ptr(arg), _stream())
+    _lib.check(rc, "roi_pool")
+    return out, arg
+
+
+def infer_scale(feature_hw, image_hw):
+    """torchvision poolers._infer_scale: 2 ** round(log2(fp32(feat/img))); both axes must agree."""
+    scales = []
+    for s1, s2 in zip(feature_hw, image_hw):
+        approx = np.float32(float(s1) / float(s2))
+        scales.append(2.0 ** float(np.round(np.log2(approx))))
+    if scales[0] != scales[1]:
+        raise AssertionError("feature map and image disagree on the scale per axis: %r" % (scales,))
+    return scales[0]
+
+
+class MultiScaleRoIAlign(torch.nn.Module):
+    """torchvision.ops.MultiScaleRoIAlign(featmap_names, output_size, sampling_ratio) as the
+    reference uses it (ROIHead/roi_pooling.py:44-53): FPN level mapper + RoIAlign per level.
+
+    forward(x: dict[str, Tensor(B,C,h,w)], boxes: list[Tensor(P_i,4)], image_shapes: list[(h,w)])
+    -> Tensor(sum P_i, C, oh, ow).  `forward_padded` is the sync-free batched form."""
+
+    def __init__(self, featmap_names, output_size, sampling_ratio, *, canonical_scale=224, canonical_level=4):
+        super().__init__()
+        if isinstance(output_size, int):
+            output_size = (output_size, output_size)
+        self.featmap_names = list(featmap_names)
+        self.output_size = tuple(output_size)
+        self.sampling_ratio = sampling_ratio
+        if canonical_scale != 224 or canonical_level != 4:
+            raise ValueError("only the canonical (224, 4) level mapper is built into the kernel")
+
+    def _levels(self, x, image_shapes):
+        feats = [v for k, v in x.items() if k in self.featmap_names]
+        if not feats:
+            raise ValueError("none of the feature maps %r is in featmap_names %r" % (list(x), self.featmap_names))
+        max_h = max(s[0] for s in image_shapes)
+        max_w = max(s[1] for s in image_shapes)
+        scales = [infer_scale(f.shape[-2:], (max_h, max_w)) for f in feats]
+        k_min = int(-math.log2(scales[0]))
+        k_max = int(-math.log2(scales[-1]))
+        return feats, scales, k_min, k_max
+
+    def _pool(self, feats, scales, k_min, k_max, rois, n_rois):
+        K = rois.shape[0]
+        C = feats[0].shape[1]
+        if len(feats) == 1:
+            return roi_align(feats[0], rois, self.output_size, scales[0], self.sampling_ratio, n_rois=n_rois)
+        lvl = level_map(rois, k_min, k_max, n_rois)
+        out = torch.zeros((K, C) + self.output_size, dtype=torch.float32, device=rois.device)
+        for l, (f, s) in enumerate(zip(feats, scales)):
+            roi_align(f, rois, self.output_size, s, self.sampling_ratio, n_rois=n_rois, lvl=lvl, lvl_value=l, out=out)
+        return out
+
+    def forward(self, x, boxes, image_shapes):
+        feats, scales, k_min, k_max = self._levels(x, image_shapes)
+        dev = feats[0].device
+        parts = []
+        for i, b in enumerate(boxes):
+            b = b.to(device=dev, dtype=torch.float32).reshape(-1, 4)
+            parts.append(torch.cat([torch.full((b.shape[0], 1), float(i), device=dev), b], dim=1))
+        rois = torch.cat(parts, dim=0) if parts else torch.zeros((0, 5), device=dev)
+        if rois.shape[0] == 0:
+            return torch.zeros((0, feats[0].shape[1]) + self.output_size, device=dev)
+        return self._pool(feats, scales, k_min, k_max, rois, None)
+
+    def forward_padded(self, x, props, count, image_shapes):
+        """props (B,P,4) padded, count (B) int32 device -> (B*P, C, oh, ow) whose first sum(count)
+        rows are valid (same row order as forward), plus the device-side total.  No host sync."""
+        feats, scales, k_min, k_max = self._levels(x, image_shapes)
+        rois, total = build_rois(props, count)
+        return self._pool(feats, scales, k_min, k_max, rois, total), total
