@@ -36,7 +36,7 @@ class RPN(Module):
         """(A,4) anchors shared by the batch when the generator returns stride-0 expands (ours and
         the reference's do, anchor_generator.py:119); otherwise a contiguous (B,A,4)."""
         list_anchors = self.anchor_generator(batch_image_info, list_features)
-        if all(a.stride(0) == 0 for a in list_anchors):
+        if all(a.stride(0) == 0 or a.shape[0] == 1 for a in list_anchors):
             return list_anchors, torch.cat([a[0].reshape(-1, 4) for a in list_anchors], dim=0)
         return list_anchors, torch.cat([a.flatten(1, 2) for a in list_anchors], dim=1).contiguous()
 

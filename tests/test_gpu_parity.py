@@ -66,7 +66,7 @@ def test_anchor_generator_golden(dev, name):
     assert_bits_equal(ag.base_anchor.cpu().numpy(), g[f"{name}.base"])
     for l, a in enumerate(res):
         assert tuple(a.shape) == tuple(g[f"{name}.l{l}.shape"])
-        assert a.stride(0) == 0
+        assert a.stride(0) == 0 or info[0] == 1
         a0 = a[0].cpu().numpy()
         assert int(bits(a0).astype(np.int64).sum()) == int(g[f"{name}.l{l}.checksum"])
         if f"{name}.l{l}.full" in g:
