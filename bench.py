@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""Benchmark of the Faster R-CNN proposal + RoI-pool hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic RPN-head outputs and feature maps
+already resident in HBM:  flatten -> per-image top-k (12000) -> decode / clip / small-box filter ->
+NMS (0.7, keep 2000) -> gather -> RoI list -> RoIAlign 7x7 (C=512).  Workload = BASELINE.json
+configs[1] as made concrete in SURVEY.md 8(d) "config 2": batch 16 synthetic 600x1000 images per
+GPU, one stride-16 map 37x62, A = 20,646 anchors/image, reference (bug-compatible) decode.
+For N > 1 every rank runs its own 16 images (weak scaling, no collective inside the timed region;
+one RCCL all_gather of the padded proposals afterwards, timed separately).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel of the step as measured with
+HIP events on the launch stream inside the timed region; `cpu_baseline` times the CPU oracle
+(oracle/, a C restatement of the reference's algorithm) on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+IMG_H, IMG_W, FH, FW, NA, C = 600, 1000, 37, 62, 9, 512
+A = FH * FW * NA
+PRE_NMS, POST_NMS, NMS_THR, MIN_SIZE = 12000, 2000, 0.7, 1e-3
+
+
+def synth_image(index):
+    """SURVEY.md 8(d) config 1/2 inputs for one image: tie-free logits, N(0,.1)/N(0,.2) deltas."""
+    g = torch.Generator().manual_seed(1234 + index)
+    cls = (((torch.randperm(A, generator=g).float() / A) - 0.5) * 8).reshape(FH, FW, NA).permute(2, 0, 1).contiguous()
+    reg = torch.randn(4 * NA, FH, FW, generator=g)
+    reg[0::4] *= 0.1
+    reg[1::4] *= 0.1
+    reg[2::4] *= 0.2
+    reg[3::4] *= 0.2
+    feat = torch.randn(C, FH, FW, generator=g)
+    return cls, reg, feat
+
+
+def make_batch(first_index, batch):
+    items = [synth_image(first_index + i) for i in range(batch)]
+    return (torch.stack([i[0] for i in items]), torch.stack([i[1] for i in items]),
+            torch.stack([i[2] for i in items]))
+
+
+class Path:
+    """The hot path on one GPU, stage by stage so that each stage can be bracketed by events."""
+
+    def __init__(self, dev, textbook=False):
+        from objectdetection_amd import ops
+        from objectdetection_amd.RPN.anchor_generator import AnchorGenerator
+        from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+        self.ops = ops
+        self.dev = dev
+        self.ag = AnchorGenerator()
+        self.pool = ROIPooling(['1'], [7, 7], 2)
+        self.textbook = textbook
+
+    def anchors(self, batch, feat):
+        return torch.cat([a[0].reshape(-1, 4) for a in self.ag((batch, IMG_H, IMG_W), [feat])], 0)
+
+    def step(self, anchors, cls, reg, feat, ev=None):
+        ops = self.ops
+
+        def mark(name):
+            if ev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                ev.append((name, e))
+
+        mark("start")
+        scores, deltas = ops.rpn_flatten([cls], [reg])
+        mark("flatten")
+        top_val, top_idx = ops.topk_desc(scores, PRE_NMS)
+        mark("topk")
+        boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
+        mark("decode_clip_filter")
+        keep, n_keep = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
+        mark("nms")
+        props = ops.gather_boxes(boxes, keep, n_keep)
+        mark("gather")
+        out, total = self.pool.forward_padded({'1': feat}, props, n_keep, [(IMG_H, IMG_W)])
+        mark("roi_align")
+        return props, n_keep, out, total
+
+
+def cpu_baseline(batch_sample, threads):
+    """Times the CPU oracle on `batch_sample` images of the same workload (full path)."""
+    from oracle import oracle as orc
+    orc.build()
+    orc.set_threads(threads)
+    params = dict(num_pre_nms=PRE_NMS, num_post_nms=POST_NMS, nms_threshold=NMS_THR, proposal_min_size=MIN_SIZE)
+    imgs = [synth_image(i) for i in range(batch_sample)]
+
+    def one(i):
+        cls, reg, feat = imgs[i]
+        props = orc.rpn_proposals((1, IMG_H, IMG_W), [cls[None].numpy()], [reg[None].numpy()], params)
+        out, _ = orc.multiscale_roi_align([feat[None].numpy()], props, [(IMG_H, IMG_W)], (7, 7), 2)
+        return len(props[0]), out
+
+    one(0)  # warm-up
+    t0 = time.perf_counter()
+    rois = 0
+    for i in range(batch_sample):
+        n, _ = one(i)
+        rois += n
+    dt = time.perf_counter() - t0
+    return dict(value=batch_sample / dt, unit="images/s", cores=threads, kind="port",
+                sample="%d images of the same workload (full path incl. RoIAlign C=%d), oracle/frcnn_oracle.c with "
+                       "OpenMP on RoIAlign, %.2f s, %d RoIs" % (batch_sample, C, dt, rois))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="images timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the NMS microbenchmarks")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from objectdetection_amd import _lib
+    _lib.load()
+    path = Path(dev)
+    B = args.batch
+    cls, reg, feat = (t.to(dev) for t in make_batch(rank * B, B))
+    anchors = path.anchors(B, feat)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        path.step(anchors, cls, reg, feat)
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev = []
+        props, n_keep, out, total = path.step(anchors, cls, reg, feat, ev)
+        events.append(ev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-stage device time from the events recorded inside the timed region
+    stage_ms = {}
+    for ev in events:
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stage_ms.setdefault(n1, []).append(e0.elapsed_time(e1))
+    stage_ms = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+    counts = n_keep.tolist()
+    n_rois = int(total.item())
+
+    # final gather of per-image proposals over RCCL (outside the timed region)
+    gather_ms = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        all_props = [torch.empty_like(props) for _ in range(world)]
+        all_counts = [torch.empty_like(n_keep) for _ in range(world)]
+        dist.all_gather(all_props, props)
+        dist.all_gather(all_counts, n_keep)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        extras = nms_microbench(path, dev)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        # dominant kernel + its roofline (algorithmic bytes per launch / mean launch duration)
+        dominant = max(stage_ms, key=stage_ms.get)
+        roi_bytes = n_rois * C * 49 * 4 + B * C * FH * FW * 4 + n_rois * 20  # write + feature read + rois
+        ra_ms = stage_ms["roi_align"]
+        roofline = dict(bound="hbm", kernel="roi_align (incl. build_rois)", achieved=roi_bytes / (ra_ms * 1e-3) / 1e9,
+                        peak=HBM_PEAK_GBPS, unit="GB/s", traffic=None,
+                        algorithmic_bytes_per_launch=roi_bytes, launch_ms=ra_ms, dominant_stage=dominant)
+        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBPS
+        path_bytes = roi_bytes + B * (A * 4 + PRE_NMS * 8 + PRE_NMS * 32 + PRE_NMS * 20 + PRE_NMS * 20 + POST_NMS * 24)
+        line = {
+            "metric": "images/sec RPN proposal+RoIPool",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] / SURVEY 8d config 2: batch %d x 600x1000 per GPU, 37x62 stride-16 "
+                                   "map, A=%d anchors/img, top-%d -> NMS %.1f -> <=%d, RoIAlign 7x7 C=%d, "
+                                   "reference (bug-compatible) decode" % (B, A, PRE_NMS, NMS_THR, POST_NMS, C),
+                       "batch_per_gpu": B, "parallelism": "image-sharded x%d" % world,
+                       "proposals_per_image_mean": float(np.mean(counts)), "rois_per_step": n_rois},
+            "stage_ms": stage_ms,
+            "path_hbm_frac": path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "roofline": roofline,
+            "gather_ms": gather_ms,
+        }
+        line.update(extras)
+        if args.cpu_sample > 0 and world == 1:
+            threads = min(os.cpu_count() or 1, 16)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def nms_microbench(path, dev):
+    """'NMS ms/img at 20k anchors': NMS alone (mask + scan) on n = 12,000 pre-sorted boxes per image,
+    batch 16, three box sets: realistic, bug-compatible decode output, lattice."""
+    ops = path.ops
+    rng = np.random.default_rng(0)
+    n, B = PRE_NMS, 16
+
+    def realistic():
+        cx, cy = rng.uniform(0, IMG_W, n), rng.uniform(0, IMG_H, n)
+        w, h = 16 * 2 ** rng.uniform(0, 5, n), 16 * 2 ** rng.uniform(0, 5, n)
+        b = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+        b[:, 0::2] = b[:, 0::2].clip(0, IMG_W)
+        b[:, 1::2] = b[:, 1::2].clip(0, IMG_H)
+        return b.astype(np.float32)
+
+    def lattice():
+        side = int(np.ceil(np.sqrt(n)))
+        ys, xs = np.divmod(np.arange(n), side)
+        return np.stack([xs * 5.0, ys * 5.0, xs * 5.0 + 4, ys * 5.0 + 4], 1).astype(np.float32)
+
+    sets = {"realistic": torch.as_tensor(np.stack([realistic() for _ in range(B)])).to(dev),
+            "lattice": torch.as_tensor(np.stack([lattice() for _ in range(B)])).to(dev)}
+    res = {}
+    for name, boxes in sets.items():
+        for _ in range(3):
+            keep, nk = ops.nms_sorted(boxes, None, NMS_THR, POST_NMS)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 10
+        for _ in range(reps):
+            keep, nk = ops.nms_sorted(boxes, None, NMS_THR, POST_NMS)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = {"ms_per_img": e0.elapsed_time(e1) / reps / B, "keeps_mean": float(nk.float().mean())}
+    return {"nms_ms_per_img_n12000_batch16": res}
+
+
+if __name__ == "__main__":
+    main()
