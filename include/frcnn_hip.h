@@ -149,6 +149,19 @@ int frcnn_roi_align_f32(const float *feat, int B, int C, int H, int W, const flo
                         float spatial_scale, int sampling_ratio, const int32_t *lvl, int lvl_value,
                         float *out, void *stream);
 
+/* Batched form of one MultiScaleRoIAlign level pass over zero-padded proposals, the sync-free
+ * path used by RPN -> ROIHead hand-off (ROIHead/roi_head.py:127-130).  props: (B,P,4);
+ * count: (B) valid rows per image or NULL (= P).  Output rows are compacted in image order,
+ * row(b,j) = sum(count[:b]) + j, exactly the row order of torchvision's concatenated roi list.
+ * n_levels == 1: every RoI is pooled from `feat` at `spatial_scale`.  n_levels > 1: a RoI is
+ * pooled only when its LevelMapper level (k_min,k_max as in frcnn_level_map_f32) equals `level`;
+ * the level-0 call also zero-fills the rows no level takes (torchvision's zeros background).
+ * total_out: (1) int32 = sum(count), or NULL.  out: (>= sum(count), C, pooled_h, pooled_w). */
+int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W, const float *props,
+                                const int32_t *count, int P, int pooled_h, int pooled_w,
+                                float spatial_scale, int sampling_ratio, int level, int n_levels,
+                                int k_min, int k_max, float *out, int32_t *total_out, void *stream);
+
 /* torchvision roi_pool (max) -- north_star extra, not called by the reference.
  * out: (K,C,ph,pw) fp32; argmax: (K,C,ph,pw) int32 flat index h*W+w, -1 for an empty bin. */
 int frcnn_roi_pool_f32(const float *feat, int B, int C, int H, int W, const float *rois, int K,

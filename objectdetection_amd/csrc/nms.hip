@@ -150,6 +150,129 @@ nms_scan_kernel(const unsigned long long *__restrict__ mask, const int32_t *__re
     if (threadIdx.x == 0) n_keep_out[b] = s_nkeep;
 }
 
+// ---- lazy ("pull") NMS ------------------------------------------------------------------------
+// One 1024-thread workgroup per image, no suppression matrix at all.  The kept boxes live in LDS.
+// For each block of 64 candidates (lane = candidate):
+//   1. pull   : all 16 waves test the 64 candidates against the boxes kept so far (wave w takes
+//               kept rows w, w+16, ...; kept box broadcast from LDS) -> ballot -> LDS atomicOr;
+//   2. diag   : for the candidates still alive, the 16 waves compute their 64-bit intra-block
+//               suppression rows in parallel (alive candidate #a goes to wave a % 16);
+//   3. resolve: wave 0 walks the alive candidates in order with scalar ffs / readlane / or, and
+//               appends the survivors to the kept list.
+// Work = (kept so far) x 64 pairs per block, and the loop stops at max_keep keeps, so only the
+// part of the IoU matrix that greedy NMS actually consults is ever evaluated (a few million pairs
+// instead of n^2/2 = 72 M at n = 12,000).  Same fp32 IoU expression, same threshold rule.
+#define NMS_LAZY_THREADS 1024
+#define NMS_LAZY_WAVES 16
+#define NMS_LAZY_LDS_LIMIT (128 * 1024)
+
+__device__ __forceinline__ float lane_bcast(float v, int src_lane)
+{
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src_lane));
+}
+
+__global__ void __launch_bounds__(NMS_LAZY_THREADS)
+nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image, int max_n,
+                float thr, int max_keep, int cap, int32_t *__restrict__ keep_out,
+                int32_t *__restrict__ n_keep_out)
+{
+    extern __shared__ float4 s_kbox[]; // [cap] kept boxes, followed by [cap] areas; cap = min(max_keep, max_n)
+    float *s_karea = (float *)(s_kbox + cap);
+    __shared__ unsigned long long s_row[64];
+    __shared__ unsigned s_rem[2];
+    __shared__ int s_nkeep;
+    const int b = blockIdx.x;
+    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
+    const int Wn = (n + 63) >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const float4 *bx = boxes + (long long)b * max_n;
+    int32_t *keep = keep_out + (long long)b * max_keep;
+    if (threadIdx.x == 0) {
+        s_nkeep = 0;
+        s_rem[0] = 0;
+        s_rem[1] = 0;
+    }
+    __syncthreads();
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 cb = lane < n ? bx[lane] : zero4;
+    for (int c = 0; c < Wn; ++c) {
+        const int nxt = (c + 1) * 64 + lane;
+        const float4 nb = nxt < n ? bx[nxt] : zero4; // prefetch the next block's candidates
+        const float carea = frcnn_area(cb.x, cb.y, cb.z, cb.w);
+        const int nk = s_nkeep;
+        // 1. pull
+        bool sup = false;
+        for (int r = wave; r < nk; r += NMS_LAZY_WAVES) {
+            float4 k = s_kbox[r];
+            float iou = frcnn_iou(k.x, k.y, k.z, k.w, s_karea[r], cb.x, cb.y, cb.z, cb.w, carea);
+            sup = sup || (iou > thr);
+        }
+        unsigned long long m = __ballot(sup);
+        if (lane == 0 && m != 0) {
+            atomicOr(&s_rem[0], (unsigned)m);
+            atomicOr(&s_rem[1], (unsigned)(m >> 32));
+        }
+        __syncthreads();
+        const int rows = min(64, n - c * 64);
+        const unsigned long long valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+        unsigned long long rem =
+            uniform64((((unsigned long long)s_rem[1] << 32) | s_rem[0]) | ~valid);
+        const unsigned long long alive = ~rem;
+        // 2. diag rows of the alive candidates, spread over the waves
+        {
+            unsigned long long rest = alive;
+            int a = 0;
+            while (rest != 0) {
+                int i = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                if ((a & (NMS_LAZY_WAVES - 1)) == wave) {
+                    float rx1 = lane_bcast(cb.x, i), ry1 = lane_bcast(cb.y, i);
+                    float rx2 = lane_bcast(cb.z, i), ry2 = lane_bcast(cb.w, i);
+                    float rarea = lane_bcast(carea, i);
+                    float iou = frcnn_iou(rx1, ry1, rx2, ry2, rarea, cb.x, cb.y, cb.z, cb.w, carea);
+                    unsigned long long w = __ballot(lane > i && iou > thr);
+                    if (lane == 0) s_row[i] = w;
+                }
+                ++a;
+            }
+        }
+        __syncthreads();
+        // 3. resolve
+        if (wave == 0) {
+            const unsigned long long myrow = s_row[lane];
+            unsigned long long K = 0;
+            unsigned long long cand = alive;
+            int room = max_keep - nk;
+            while (cand != 0 && room > 0) {
+                int i = __ffsll((long long)cand) - 1;
+                K |= 1ull << i;
+                --room;
+                unsigned lo = __builtin_amdgcn_readlane((unsigned)myrow, i);
+                unsigned hi = __builtin_amdgcn_readlane((unsigned)(myrow >> 32), i);
+                rem |= ((unsigned long long)hi << 32) | lo;
+                unsigned long long above = i >= 63 ? 0ull : (~0ull << (i + 1));
+                cand = uniform64(~rem & above);
+            }
+            if ((K >> lane) & 1ull) {
+                int pos = nk + __popcll(K & ((1ull << lane) - 1ull));
+                s_kbox[pos] = cb;
+                s_karea[pos] = carea;
+                keep[pos] = c * 64 + lane;
+            }
+            if (lane == 0) {
+                s_nkeep = nk + __popcll(K);
+                s_rem[0] = 0;
+                s_rem[1] = 0;
+            }
+        }
+        __syncthreads();
+        if (s_nkeep >= max_keep) break;
+        cb = nb;
+    }
+    if (threadIdx.x == 0) n_keep_out[b] = s_nkeep;
+}
+
 extern "C" size_t frcnn_nms_workspace_bytes(int B, int max_n)
 {
     if (B <= 0 || max_n <= 0) return 0;
@@ -178,17 +301,40 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
         FRCNN_REQUIRE(e == hipSuccess, "nms: memset failed: %s", hipGetErrorString(e));
         return FRCNN_OK;
     }
-    FRCNN_REQUIRE(boxes && keep_out && workspace, "nms: null pointer");
+    FRCNN_REQUIRE(boxes && keep_out, "nms: null pointer");
     FRCNN_REQUIRE(iou_threshold == iou_threshold, "nms: NaN threshold");
+    FRCNN_REQUIRE(B <= 65535, "nms: batch too large");
+    const float thr = threshold_round_down(iou_threshold);
+
+    // Lazy path: the kept list (20 B per keep) must fit in LDS.  keep_out has max_keep columns,
+    // but no more than max_n boxes can ever be kept.
+    const int cap = max_keep < max_n ? max_keep : max_n;
+    const size_t lazy_lds = (size_t)cap * 20;
+    if (lazy_lds <= NMS_LAZY_LDS_LIMIT) {
+        static size_t configured = 48 * 1024;
+        if (lazy_lds > configured) {
+            hipError_t e = hipFuncSetAttribute((const void *)nms_lazy_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               NMS_LAZY_LDS_LIMIT);
+            FRCNN_REQUIRE(e == hipSuccess, "nms: cannot reserve LDS: %s", hipGetErrorString(e));
+            configured = NMS_LAZY_LDS_LIMIT;
+        }
+        hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds,
+                           (hipStream_t)stream, (const float4 *)boxes, n_per_image, max_n, thr,
+                           max_keep, cap, keep_out, n_keep_out);
+        FRCNN_CHECK_LAUNCH("nms_lazy");
+        return FRCNN_OK;
+    }
+
+    // Bitmask path (very large keep budgets): full upper-triangular suppression matrix + scan.
+    FRCNN_REQUIRE(workspace, "nms: null workspace");
     if (workspace_bytes < frcnn_nms_workspace_bytes(B, max_n)) {
         frcnn_set_error("nms: workspace too small (%zu < %zu)", workspace_bytes,
                         frcnn_nms_workspace_bytes(B, max_n));
         return FRCNN_EWORKSPACE;
     }
     const int W = (max_n + 63) / 64;
-    FRCNN_REQUIRE((size_t)W * 8 <= 96 * 1024, "nms: max_n too large for the scan's LDS bitmap");
-    FRCNN_REQUIRE(B <= 65535, "nms: batch too large");
-    const float thr = threshold_round_down(iou_threshold);
+    FRCNN_REQUIRE((size_t)W * 8 <= 60 * 1024, "nms: max_n too large for the scan's LDS bitmap");
     int col_groups = (W + 4 * NMS_COL_WAVES - 1) / (4 * NMS_COL_WAVES); // ~4 column blocks per wave
     if (col_groups < 1) col_groups = 1;
     if (col_groups > 64) col_groups = 64;

@@ -217,6 +217,307 @@ extern "C" int frcnn_roi_align_f32(const float *feat, int B, int C, int H, int W
     return FRCNN_OK;
 }
 
+// ---- batched RoIAlign over padded proposals ---------------------------------------------------
+// The fast path of the headline workload.  One workgroup owns (image b, CC-channel chunk, RoI
+// split): it first copies its CC feature planes into LDS, channel-interleaved in groups of four
+// ([group][pixel] of float4), then sweeps its RoIs.  A lane produces one (RoI, 4 channels, bin)
+// item: 2x2 bilinear samples x 4 taps, each tap ONE ds_read_b128 that serves 4 channels, i.e. the
+// 16 taps per output come from LDS (256 B/clk/CU) instead of the vector L1 (64 B/clk/CU), and HBM
+// sees the feature map once plus the output stream.  Lanes run over bins fastest, so each of the
+// four stores of an item lands in a 196-byte contiguous run of the (K, C, 7, 7) output.
+
+__device__ __forceinline__ int map_level(float4 p, int k_min, int k_max)
+{
+    float area = (p.z - p.x) * (p.w - p.y);
+    float s = sqrtf(area);
+    float t = floorf((4.0f + log2f(s / 224.0f)) + 1e-6f);
+    if (!(t == t)) return -1;
+    t = t < (float)k_min ? (float)k_min : t;
+    t = t > (float)k_max ? (float)k_max : t;
+    return (int)t - k_min;
+}
+
+struct AxisSample { // one 1-D bilinear sample: taps lo/hi with weights (zero when out of range)
+    int lo, hi;
+    float wlo, whi;
+};
+
+__device__ __forceinline__ AxisSample axis_sample(float v, int n)
+{
+    AxisSample a;
+    bool ok = !(v < -1.0f || v > (float)n);
+    if (v <= 0.0f) v = 0.0f;
+    int lo = (int)v, hi;
+    if (lo >= n - 1) {
+        hi = lo = n - 1;
+        v = (float)lo;
+    } else {
+        hi = lo + 1;
+    }
+    float l = v - (float)lo;
+    float h = 1.0f - l;
+    a.lo = ok ? lo : 0;
+    a.hi = ok ? hi : 0;
+    a.wlo = ok ? h : 0.0f;
+    a.whi = ok ? l : 0.0f;
+    return a;
+}
+
+#define RAP_THREADS 512
+
+__global__ void __launch_bounds__(RAP_THREADS)
+roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
+                       const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
+                       int CC, float scale, int level, int n_levels, int k_min, int k_max,
+                       float *__restrict__ out, int32_t *__restrict__ total_out)
+{
+    extern __shared__ float4 s_plane[]; // [G][H*W]
+    __shared__ int s_off, s_cnt;
+    const int b = blockIdx.z;
+    const int B = gridDim.z;
+    const int c0 = blockIdx.x * CC;
+    const int nc = min(CC, C - c0);
+    const int G = (nc + 3) >> 2;
+    const int HW = H * W;
+    if (threadIdx.x == 0) {
+        int off = 0, tot = 0;
+        for (int i = 0; i < B; ++i) {
+            int c = count ? count[i] : P;
+            c = c < 0 ? 0 : (c > P ? P : c);
+            if (i < b) off += c;
+            if (i == b) s_cnt = c;
+            tot += c;
+        }
+        s_off = off;
+        if (total_out && blockIdx.x == 0 && blockIdx.y == 0 && b == 0) *total_out = tot;
+    }
+    // stage the chunk's planes: 4 coalesced plane reads -> one 16-byte LDS write per pixel/group
+    const float *fb = feat + ((long long)b * C + c0) * HW;
+    for (int t = threadIdx.x; t < G * HW; t += RAP_THREADS) {
+        int g = t / HW;
+        int p = t - g * HW;
+        const float *f = fb + (long long)(4 * g) * HW + p;
+        float4 v;
+        v.x = f[0];
+        v.y = 4 * g + 1 < nc ? f[HW] : 0.0f;
+        v.z = 4 * g + 2 < nc ? f[2 * HW] : 0.0f;
+        v.w = 4 * g + 3 < nc ? f[3 * HW] : 0.0f;
+        s_plane[t] = v;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    const int per = (cnt + gridDim.y - 1) / gridDim.y;
+    const int j0 = blockIdx.y * per;
+    const int j1 = min(cnt, j0 + per);
+    if (j0 >= j1) return;
+    const int items_per_roi = G * 49;
+    const int items = (j1 - j0) * items_per_roi;
+    const float4 *pb = props + (long long)b * P;
+    float *ob = out + ((long long)s_off * C + c0) * 49;
+    const float inv_items = 1.0f / (float)items_per_roi;
+    for (int t = threadIdx.x; t < items; t += RAP_THREADS) {
+        // t / items_per_roi via a float reciprocal + fix-up (items < 2^23; host checks P*G*49)
+        int jl = (int)(((float)t + 0.5f) * inv_items);
+        int rem = t - jl * items_per_roi;
+        if (rem < 0) {
+            --jl;
+            rem += items_per_roi;
+        } else if (rem >= items_per_roi) {
+            ++jl;
+            rem -= items_per_roi;
+        }
+        int g = rem / 49;
+        int bin = rem - g * 49;
+        int ph = bin / 7, pw = bin - ph * 7;
+        int j = j0 + jl;
+        float4 box = pb[j];
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        bool write = true;
+        if (n_levels > 1) {
+            int lv = map_level(box, k_min, k_max);
+            bool none = lv < 0 || lv >= n_levels; // no level takes it: level 0's pass writes zeros
+            write = (lv == level) || (none && level == 0);
+            if (none) box = make_float4(0.0f, 0.0f, -1.0f, -1.0f), lv = -2;
+            if (lv != level) goto store;
+        }
+        {
+            float start_w = box.x * scale, start_h = box.y * scale;
+            float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
+            roi_w = roi_w > 1.0f ? roi_w : 1.0f;
+            roi_h = roi_h > 1.0f ? roi_h : 1.0f;
+            float bin_h = roi_h / 7.0f, bin_w = roi_w / 7.0f;
+            AxisSample ys[2], xs[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
+                xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
+            }
+            const float4 *pl = s_plane + g * HW;
+#pragma unroll
+            for (int iy = 0; iy < 2; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix < 2; ++ix) {
+                    float4 f1 = pl[ys[iy].lo * W + xs[ix].lo];
+                    float4 f2 = pl[ys[iy].lo * W + xs[ix].hi];
+                    float4 f3 = pl[ys[iy].hi * W + xs[ix].lo];
+                    float4 f4 = pl[ys[iy].hi * W + xs[ix].hi];
+                    float w1 = ys[iy].wlo * xs[ix].wlo, w2 = ys[iy].wlo * xs[ix].whi;
+                    float w3 = ys[iy].whi * xs[ix].wlo, w4 = ys[iy].whi * xs[ix].whi;
+                    acc.x = fmaf(w4, f4.x, fmaf(w3, f3.x, fmaf(w2, f2.x, fmaf(w1, f1.x, acc.x))));
+                    acc.y = fmaf(w4, f4.y, fmaf(w3, f3.y, fmaf(w2, f2.y, fmaf(w1, f1.y, acc.y))));
+                    acc.z = fmaf(w4, f4.z, fmaf(w3, f3.z, fmaf(w2, f2.z, fmaf(w1, f1.z, acc.z))));
+                    acc.w = fmaf(w4, f4.w, fmaf(w3, f3.w, fmaf(w2, f2.w, fmaf(w1, f1.w, acc.w))));
+                }
+            }
+            acc.x *= 0.25f;
+            acc.y *= 0.25f;
+            acc.z *= 0.25f;
+            acc.w *= 0.25f;
+        }
+    store:
+        if (write) {
+            float *o = ob + ((long long)j * C + 4 * g) * 49 + bin;
+            o[0] = acc.x;
+            if (4 * g + 1 < nc) o[49] = acc.y;
+            if (4 * g + 2 < nc) o[98] = acc.z;
+            if (4 * g + 3 < nc) o[147] = acc.w;
+        }
+    }
+}
+
+// Generic batched fallback (any pooled size / sampling ratio / plane size): block = (RoI split,
+// 32-channel chunk, image); per RoI the sample table is rebuilt in LDS, taps come through L1.
+__global__ void __launch_bounds__(256)
+roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, int W,
+                                const float4 *__restrict__ props, const int32_t *__restrict__ count,
+                                int P, int pooled_h, int pooled_w, float scale, int sampling_ratio,
+                                int level, int n_levels, int k_min, int k_max,
+                                float *__restrict__ out, int32_t *__restrict__ total_out)
+{
+    __shared__ Sample s_samp[RA_MAX_SAMPLES];
+    __shared__ int s_off, s_cnt;
+    const int b = blockIdx.z;
+    const int B = gridDim.z;
+    if (threadIdx.x == 0) {
+        int off = 0, tot = 0;
+        for (int i = 0; i < B; ++i) {
+            int c = count ? count[i] : P;
+            c = c < 0 ? 0 : (c > P ? P : c);
+            if (i < b) off += c;
+            if (i == b) s_cnt = c;
+            tot += c;
+        }
+        s_off = off;
+        if (total_out && blockIdx.x == 0 && blockIdx.y == 0 && b == 0) *total_out = tot;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    const int bins = pooled_h * pooled_w;
+    const int per_bin = sampling_ratio * sampling_ratio;
+    const int nsamp = bins * per_bin;
+    const int c0 = blockIdx.y * RA_CHUNK;
+    const int nc = min(RA_CHUNK, C - c0);
+    const float *fb = feat + ((long long)b * C + c0) * H * W;
+    for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
+        float4 box = props[(long long)b * P + j];
+        float *ob = out + ((long long)(s_off + j) * C + c0) * bins;
+        if (n_levels > 1) {
+            int lv = map_level(box, k_min, k_max);
+            bool none = lv < 0 || lv >= n_levels;
+            if (none && level == 0)
+                for (int t = threadIdx.x; t < nc * bins; t += blockDim.x) ob[t] = 0.0f;
+            if (lv != level) continue;
+        }
+        float start_w = box.x * scale, start_h = box.y * scale;
+        float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
+        roi_w = roi_w > 1.0f ? roi_w : 1.0f;
+        roi_h = roi_h > 1.0f ? roi_h : 1.0f;
+        float bin_h = roi_h / (float)pooled_h, bin_w = roi_w / (float)pooled_w;
+        __syncthreads(); // previous RoI's readers are done with s_samp
+        for (int t = threadIdx.x; t < nsamp; t += blockDim.x) {
+            int bin = t / per_bin;
+            int si = t - bin * per_bin;
+            int iy = si / sampling_ratio, ix = si - iy * sampling_ratio;
+            int ph = bin / pooled_w, pw = bin - ph * pooled_w;
+            float yy = start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)sampling_ratio;
+            float xx = start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)sampling_ratio;
+            s_samp[t] = make_sample(yy, xx, H, W);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nc * bins; t += blockDim.x) {
+            int c = t / bins;
+            int bin = t - c * bins;
+            const float *f = fb + (long long)c * H * W;
+            float acc = 0.0f;
+            const Sample *sp = s_samp + bin * per_bin;
+            for (int si = 0; si < per_bin; ++si) {
+                Sample s = sp[si];
+                acc += s.w1 * f[s.p1] + s.w2 * f[s.p2] + s.w3 * f[s.p3] + s.w4 * f[s.p4];
+            }
+            ob[t] = acc / (float)per_bin;
+        }
+    }
+}
+
+#define RAP_LDS_BUDGET (150 * 1024)
+
+extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W,
+                                           const float *props, const int32_t *count, int P,
+                                           int pooled_h, int pooled_w, float spatial_scale,
+                                           int sampling_ratio, int level, int n_levels, int k_min,
+                                           int k_max, float *out, int32_t *total_out, void *stream)
+{
+    FRCNN_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0 && P >= 0 && pooled_h > 0 && pooled_w > 0,
+                  "roi_align_batched: bad shape");
+    FRCNN_REQUIRE(n_levels >= 1 && level >= 0 && level < n_levels, "roi_align_batched: bad level");
+    if (P == 0) {
+        if (total_out) {
+            hipError_t e = hipMemsetAsync(total_out, 0, sizeof(int32_t), (hipStream_t)stream);
+            FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: memset failed");
+        }
+        return FRCNN_OK;
+    }
+    FRCNN_REQUIRE(feat && props && out, "roi_align_batched: null pointer");
+    FRCNN_REQUIRE((long long)H * W < (1ll << 30), "roi_align_batched: feature plane too large");
+    FRCNN_REQUIRE(sampling_ratio >= 1, "roi_align_batched: sampling_ratio must be >= 1 (got %d)", sampling_ratio);
+    FRCNN_REQUIRE((long long)pooled_h * pooled_w * sampling_ratio * sampling_ratio <= RA_MAX_SAMPLES,
+                  "roi_align_batched: pooled_h*pooled_w*sampling_ratio^2 exceeds %d", RA_MAX_SAMPLES);
+    const long long plane_bytes = (long long)H * W * 4;
+    if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && plane_bytes * 4 <= RAP_LDS_BUDGET &&
+        (long long)P * 4 * 49 < (1ll << 23)) {
+        int CC = 16;
+        while (CC > 4 && plane_bytes * CC > RAP_LDS_BUDGET) CC >>= 1;
+        if (CC > C) CC = (C + 3) / 4 * 4;
+        const int chunks = (C + CC - 1) / CC;
+        // enough RoI splits that the grid covers the chip a few times over
+        int splits = (4 * 256 + chunks * B - 1) / (chunks * B);
+        if (splits < 1) splits = 1;
+        if (splits > 16) splits = 16;
+        size_t lds = (size_t)plane_bytes * (size_t)CC;
+        static size_t configured = 0;
+        if (lds > configured) {
+            hipError_t e = hipFuncSetAttribute((const void *)roi_align_plane_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
+                          hipGetErrorString(e));
+            configured = lds;
+        }
+        hipLaunchKernelGGL(roi_align_plane_kernel, dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
+                           (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
+                           spatial_scale, level, n_levels, k_min, k_max, out, total_out);
+        FRCNN_CHECK_LAUNCH("roi_align_plane");
+        return FRCNN_OK;
+    }
+    int chunks = (C + RA_CHUNK - 1) / RA_CHUNK;
+    int splits = P < 128 ? P : 128;
+    hipLaunchKernelGGL(roi_align_batched_direct_kernel, dim3(splits, chunks, B), dim3(256), 0,
+                       (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, pooled_h,
+                       pooled_w, spatial_scale, sampling_ratio, level, n_levels, k_min, k_max, out,
+                       total_out);
+    FRCNN_CHECK_LAUNCH("roi_align_batched_direct");
+    return FRCNN_OK;
+}
+
 // ---- max RoIPool (torchvision roi_pool semantics; not called by the reference) -----------------
 __global__ void __launch_bounds__(256)
 roi_pool_kernel(const float *__restrict__ feat, int B, int C, int H, int W,

@@ -75,17 +75,26 @@ extern "C" int frcnn_rpn_flatten_f32(const float *cls, const float *reg, int B, 
 #define TOPK_THREADS 1024
 #define TOPK_WAVES 16
 
-// Adds 1 to hist[digit] for every active lane with one LDS atomic per distinct digit in the wave.
+// Lanes of the wave that are active and hold the same 8-bit digit as this lane ("match any"),
+// built from 8 ballots: constant cost whatever the digit distribution.
+__device__ __forceinline__ unsigned long long wave_match8(unsigned digit, bool active)
+{
+    unsigned long long peers = __ballot(active);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+        bool one = (digit >> bit) & 1u;
+        unsigned long long bm = __ballot(one);
+        peers &= one ? bm : ~bm;
+    }
+    return peers;
+}
+
+// Adds 1 to hist[digit] for every active lane: one LDS atomic per distinct digit in the wave.
 __device__ __forceinline__ void wave_hist_add(unsigned *hist, unsigned digit, bool active)
 {
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        int leader = __ffsll((long long)todo) - 1;
-        unsigned d = __shfl(digit, leader);
-        unsigned long long same = __ballot(active && digit == d) & todo;
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
-        todo &= ~same;
-    }
+    unsigned long long peers = wave_match8(digit, active);
+    int lane = threadIdx.x & 63;
+    if (active && (peers & ((1ull << lane) - 1ull)) == 0) atomicAdd(&hist[digit], (unsigned)__popcll(peers));
 }
 
 __global__ void __launch_bounds__(TOPK_THREADS)
@@ -125,16 +134,30 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
             wave_hist_add(s_hist, dg, act);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned cum = 0;
-            int d = 255;
-            for (; d > 0; --d) {
-                unsigned h = s_hist[d];
-                if (cum + h >= remaining) break;
-                cum += h;
+        if (wave == 0) {
+            // suffix sums over the 256 bins, 4 bins per lane: S(d) = sum_{d' >= d} hist[d'].
+            // The wanted digit is the largest d with S(d) >= remaining.
+            unsigned h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2],
+                     h3 = s_hist[4 * lane + 3];
+            unsigned sum = h0 + h1 + h2 + h3;
+            unsigned incl = sum; // inclusive suffix sum over lanes (lane 63 first)
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned t = __shfl_down(incl, o);
+                if (lane + o < 64) incl += t;
             }
-            s_prefix = prefix | ((unsigned)d << shift);
-            s_remaining = remaining - cum;
+            unsigned above = incl - sum; // bins of higher lanes
+            unsigned s3 = above + h3, s2 = s3 + h2, s1 = s2 + h1, s0 = s1 + h0;
+            // S is non-increasing in d; exactly one d has S(d) >= remaining > S(d+1)
+            int d = -1;
+            unsigned cum = 0;
+            if (s3 >= remaining && above < remaining) { d = 4 * lane + 3; cum = above; }
+            else if (s2 >= remaining && s3 < remaining) { d = 4 * lane + 2; cum = s3; }
+            else if (s1 >= remaining && s2 < remaining) { d = 4 * lane + 1; cum = s2; }
+            else if (s0 >= remaining && s1 < remaining) { d = 4 * lane; cum = s1; }
+            if (d >= 0) {
+                s_prefix = prefix | ((unsigned)d << shift);
+                s_remaining = remaining - cum;
+            }
         }
         __syncthreads();
         prefix = s_prefix;
@@ -219,13 +242,7 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
             unsigned key = act ? kin[e] : 0u;
             unsigned idx = act ? iin[e] : 0u;
             unsigned dg = 255u - ((key >> shift) & 255u);
-            unsigned long long peers = __ballot(act);
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                bool one = (dg >> bit) & 1u;
-                unsigned long long bm = __ballot(one);
-                peers &= one ? bm : ~bm;
-            }
+            unsigned long long peers = wave_match8(dg, act);
             if (act) {
                 // wave-private row: all lanes read the running offset of their digit, then the
                 // first peer advances it (volatile: the next round must re-read it)

@@ -214,7 +214,8 @@ def nms_sorted(boxes, n_per_image, iou_threshold, max_keep):
     keep = torch.empty((B, max(max_keep, 1)), dtype=torch.int32, device=dev)
     n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
     lib = _lib.load()
-    nbytes = lib.frcnn_nms_workspace_bytes(B, n)
+    # the suppression-matrix workspace is only needed when the kept list cannot live in LDS
+    nbytes = lib.frcnn_nms_workspace_bytes(B, n) if min(max_keep, n) * 20 > 128 * 1024 else 0
     ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
     if n_per_image is not None and n_per_image.dtype != torch.int32:
         n_per_image = n_per_image.to(torch.int32)
@@ -411,32 +412,53 @@ class MultiScaleRoIAlign(torch.nn.Module):
         k_max = int(-math.log2(scales[-1]))
         return feats, scales, k_min, k_max
 
-    def _pool(self, feats, scales, k_min, k_max, rois, n_rois):
-        K = rois.shape[0]
+    def _pool_padded(self, feats, scales, k_min, k_max, props, count):
+        """One batched launch per level over zero-padded proposals; rows compacted in image order."""
+        B, P = props.shape[0], props.shape[1]
         C = feats[0].shape[1]
-        if len(feats) == 1:
-            return roi_align(feats[0], rois, self.output_size, scales[0], self.sampling_ratio, n_rois=n_rois)
-        lvl = level_map(rois, k_min, k_max, n_rois)
-        out = torch.zeros((K, C) + self.output_size, dtype=torch.float32, device=rois.device)
-        for l, (f, s) in enumerate(zip(feats, scales)):
-            roi_align(f, rois, self.output_size, s, self.sampling_ratio, n_rois=n_rois, lvl=lvl, lvl_value=l, out=out)
-        return out
+        dev = props.device
+        out = torch.empty((B * P, C) + self.output_size, dtype=torch.float32, device=dev)
+        total = torch.empty((1,), dtype=torch.int32, device=dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            for l, (f, s) in enumerate(zip(feats, scales)):
+                f = _f32c(f)
+                if f.shape[0] != B or f.shape[1] != C:
+                    raise ValueError("feature map %d has shape %s, expected (%d,%d,h,w)" % (l, tuple(f.shape), B, C))
+                rc = lib.frcnn_roi_align_batched_f32(
+                    _ptr(f), B, C, f.shape[2], f.shape[3], _ptr(props), _ptr(count), P, self.output_size[0],
+                    self.output_size[1], float(s), int(self.sampling_ratio), l, len(feats), int(k_min), int(k_max),
+                    _ptr(out), _ptr(total), _stream())
+                _lib.check(rc, "roi_align_batched")
+        return out, total
 
     def forward(self, x, boxes, image_shapes):
         feats, scales, k_min, k_max = self._levels(x, image_shapes)
         dev = feats[0].device
-        parts = []
+        _need_gpu(*feats)
+        B = feats[0].shape[0]
+        C = feats[0].shape[1]
+        if len(boxes) > B:
+            raise ValueError("%d box lists for a batch of %d feature maps" % (len(boxes), B))
+        counts = [int(b.shape[0]) for b in boxes] + [0] * (B - len(boxes))
+        total = sum(counts)
+        if total == 0:
+            return torch.zeros((0, C) + self.output_size, device=dev)
+        P = max(counts)
+        props = torch.zeros((B, P, 4), dtype=torch.float32, device=dev)
         for i, b in enumerate(boxes):
-            b = b.to(device=dev, dtype=torch.float32).reshape(-1, 4)
-            parts.append(torch.cat([torch.full((b.shape[0], 1), float(i), device=dev), b], dim=1))
-        rois = torch.cat(parts, dim=0) if parts else torch.zeros((0, 5), device=dev)
-        if rois.shape[0] == 0:
-            return torch.zeros((0, feats[0].shape[1]) + self.output_size, device=dev)
-        return self._pool(feats, scales, k_min, k_max, rois, None)
+            if counts[i]:
+                props[i, :counts[i]] = b.detach().to(device=dev, dtype=torch.float32).reshape(-1, 4)
+        count = torch.tensor(counts, dtype=torch.int32, device=dev)
+        out, _ = self._pool_padded(feats, scales, k_min, k_max, props, count)
+        return out[:total]
 
     def forward_padded(self, x, props, count, image_shapes):
-        """props (B,P,4) padded, count (B) int32 device -> (B*P, C, oh, ow) whose first sum(count)
-        rows are valid (same row order as forward), plus the device-side total.  No host sync."""
+        """props (B,P,4) zero-padded, count (B) int32 device (or None = P each) -> (B*P, C, oh, ow)
+        whose first sum(count) rows are valid (same row order as forward), plus the device-side
+        total.  No host sync, no intermediate roi list."""
         feats, scales, k_min, k_max = self._levels(x, image_shapes)
-        rois, total = build_rois(props, count)
-        return self._pool(feats, scales, k_min, k_max, rois, total), total
+        _need_gpu(props, count, *feats)
+        if count is not None and count.dtype != torch.int32:
+            count = count.to(torch.int32)
+        return self._pool_padded(feats, scales, k_min, k_max, _f32c(props), count)

@@ -313,6 +313,34 @@ def test_roi_align_vs_oracle(dev, oracle, C, H, W, scale, K):
     assert np.all(got[3] == 0)
 
 
+@pytest.mark.parametrize("C,H,W,Himg,Wimg,counts", [
+    (40, 37, 62, 600, 1000, [300, 0, 77]),      # LDS-plane kernel, 16-channel chunks, ragged + empty image
+    (3, 112, 112, 256, 256, [64, 32]),          # the reference's own roi_pooling smoke shapes (scale 1/2 -> fallback)
+    (33, 13, 21, 800, 1344, [50, 50]),          # odd channel count: tail chunk of 1 channel
+    (6, 50, 84, 800, 1344, [400]),              # 8-channel chunks
+])
+def test_roi_pooling_single_level_vs_oracle(dev, oracle, C, H, W, Himg, Wimg, counts):
+    """ROIPooling.forward (list API) on one level == torchvision roi_align on the concatenated list."""
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    rng = np.random.default_rng(C + H)
+    B = len(counts)
+    feat = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    props = [realistic_boxes(rng, n, Wimg, Himg) for n in counts]
+    if counts[0] >= 4:
+        props[0][0] = [0, 0, Wimg, Himg]
+        props[0][1] = [5, 5, 5, 5]
+        props[0][2] = [-40, -40, 30, 30]
+        props[0][3] = [Wimg + 50, 10, Wimg + 90, 60]
+    ref, _ = oracle.multiscale_roi_align([feat], props, [(Himg, Wimg)], (7, 7), 2)
+    pool = ROIPooling(['1'], [7, 7], 2)
+    got = pool({'1': T(feat, dev)}, [T(p, dev) for p in props], [(Himg, Wimg)])
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=1e-5)
+    # determinism of the batched kernel
+    got2 = pool({'1': T(feat, dev)}, [T(p, dev) for p in props], [(Himg, Wimg)])
+    assert torch.equal(got, got2)
+
+
 def test_multiscale_roi_align_vs_oracle(dev, oracle):
     """FPN pyramid, fine-to-coarse order: level assignment bit-exact, values 1e-5."""
     from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
