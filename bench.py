@@ -34,21 +34,61 @@ A = FH * FW * NA
 PRE_NMS, POST_NMS, NMS_THR, MIN_SIZE = 12000, 2000, 0.7, 1e-3
 
 
-def synth_image(index):
-    """SURVEY.md 8(d) config 1/2 inputs for one image: tie-free logits, N(0,.1)/N(0,.2) deltas."""
+_ANCHOR_WH = None
+
+
+def anchor_wh():
+    """fp32 (w, h) of the A anchors in flat order, from the reference's formula
+    (RPN/anchor_generator.py:59-61,86-93): host arithmetic, used only to synthesise inputs."""
+    global _ANCHOR_WH
+    if _ANCHOR_WH is None:
+        sizes = torch.tensor([128., 128., 128., 256., 256., 256., 512., 512., 512.])
+        ratios = torch.tensor([0.5, 1.0, 2.0] * 3)
+        w, h = sizes * ratios, sizes
+        base = torch.stack([-w, -h, w, h], 1) / 2
+        sy, sx = torch.tensor(IMG_H / FH, dtype=torch.float32), torch.tensor(IMG_W / FW, dtype=torch.float32)
+        gy, gx = torch.meshgrid(torch.arange(FH, dtype=torch.float32) * sy, torch.arange(FW, dtype=torch.float32) * sx,
+                                indexing="ij")
+        coord = torch.stack([gx.flatten(), gy.flatten(), gx.flatten(), gy.flatten()], 1)
+        anc = (coord[:, None, :] + base[None]).reshape(-1, 4)
+        _ANCHOR_WH = (anc[:, 2] - anc[:, 0], anc[:, 3] - anc[:, 1])
+    return _ANCHOR_WH
+
+
+def synth_image(index, workload="realistic"):
+    """Synthetic RPN-head outputs + feature map for one image (seed 1234 + index).
+
+    Logits are tie-free.  Deltas:
+      "gaussian"  -- SURVEY.md 8(d) literally: N(0, .1) for dx, dy and N(0, .2) for dw, dh.  Under the
+                     reference's decode (quirk Q1: the anchor origin is not added) every proposal lands
+                     on the image origin and NMS keeps only ~270 of 12,000.
+      "realistic" -- the deltas a trained head would have to emit UNDER THE SAME reference decode for
+                     proposals spread over the image: target centre uniform in the image, target size
+                     16 * 2^U[0,5]; dx = (cx - w_a/2) / w_a, dw = log(w_t / w_a).  NMS keeps the full
+                     2,000 proposals per image, which is the "12000 -> 2000, RoIPool 7x7" case
+                     BASELINE.json describes (206 MB of RoI features per image)."""
     g = torch.Generator().manual_seed(1234 + index)
     cls = (((torch.randperm(A, generator=g).float() / A) - 0.5) * 8).reshape(FH, FW, NA).permute(2, 0, 1).contiguous()
-    reg = torch.randn(4 * NA, FH, FW, generator=g)
-    reg[0::4] *= 0.1
-    reg[1::4] *= 0.1
-    reg[2::4] *= 0.2
-    reg[3::4] *= 0.2
+    if workload == "gaussian":
+        reg = torch.randn(4 * NA, FH, FW, generator=g)
+        reg[0::4] *= 0.1
+        reg[1::4] *= 0.1
+        reg[2::4] *= 0.2
+        reg[3::4] *= 0.2
+    else:
+        wa, ha = anchor_wh()
+        cx = torch.rand(A, generator=g) * IMG_W
+        cy = torch.rand(A, generator=g) * IMG_H
+        wt = 16 * 2 ** (torch.rand(A, generator=g) * 5)
+        ht = 16 * 2 ** (torch.rand(A, generator=g) * 5)
+        d = torch.stack([(cx - wa / 2) / wa, (cy - ha / 2) / ha, torch.log(wt / wa), torch.log(ht / ha)], 1)
+        reg = d.reshape(FH, FW, 4 * NA).permute(2, 0, 1).contiguous()  # (A,4) flat order -> (36,h,w)
     feat = torch.randn(C, FH, FW, generator=g)
     return cls, reg, feat
 
 
-def make_batch(first_index, batch):
-    items = [synth_image(first_index + i) for i in range(batch)]
+def make_batch(first_index, batch, workload="realistic"):
+    items = [synth_image(first_index + i, workload) for i in range(batch)]
     return (torch.stack([i[0] for i in items]), torch.stack([i[1] for i in items]),
             torch.stack([i[2] for i in items]))
 
@@ -94,13 +134,13 @@ class Path:
         return props, n_keep, out, total
 
 
-def cpu_baseline(batch_sample, threads):
+def cpu_baseline(batch_sample, threads, workload):
     """Times the CPU oracle on `batch_sample` images of the same workload (full path)."""
     from oracle import oracle as orc
     orc.build()
     orc.set_threads(threads)
     params = dict(num_pre_nms=PRE_NMS, num_post_nms=POST_NMS, nms_threshold=NMS_THR, proposal_min_size=MIN_SIZE)
-    imgs = [synth_image(i) for i in range(batch_sample)]
+    imgs = [synth_image(i, workload) for i in range(batch_sample)]
 
     def one(i):
         cls, reg, feat = imgs[i]
@@ -117,7 +157,57 @@ def cpu_baseline(batch_sample, threads):
     dt = time.perf_counter() - t0
     return dict(value=batch_sample / dt, unit="images/s", cores=threads, kind="port",
                 sample="%d images of the same workload (full path incl. RoIAlign C=%d), oracle/frcnn_oracle.c with "
-                       "OpenMP on RoIAlign, %.2f s, %d RoIs" % (batch_sample, C, dt, rois))
+                       "OpenMP (RoIAlign, IoU rows), %.2f s, %d RoIs" % (batch_sample, C, dt, rois))
+
+
+def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup):
+    """Warm up, then time exactly `steps` steps between barrier+synchronize pairs; max over ranks."""
+    cls, reg, feat = (t.to(dev) for t in make_batch(rank * B, B, workload))
+    anchors = path.anchors(B, feat)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        path.step(anchors, cls, reg, feat)
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev = []
+        props, n_keep, out, total = path.step(anchors, cls, reg, feat, ev)
+        events.append(ev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage_ms = {}
+    for ev in events:  # HIP events recorded on the launch stream inside the timed region
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            stage_ms.setdefault(n1, []).append(e0.elapsed_time(e1))
+    stage_ms = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+    counts = n_keep.tolist()
+    n_rois = int(total.item())
+    ms_per_step = elapsed / steps * 1e3
+    # algorithmic HBM bytes of the RoIAlign launch: output write + one read of the feature maps + RoIs
+    roi_bytes = n_rois * C * 49 * 4 + B * C * FH * FW * 4 + n_rois * 16
+    # ... and of the rest of the path (SURVEY.md 8d): scores read, top-k out, gathers, boxes, keeps
+    rest_bytes = B * (A * 4 + PRE_NMS * 8 + PRE_NMS * 32 + PRE_NMS * 20 + PRE_NMS * 20 + POST_NMS * 24)
+    ra_ms = stage_ms["roi_align"]
+    res = dict(workload=workload, value=world * B * steps / elapsed, ms_per_step=ms_per_step, stage_ms=stage_ms,
+               proposals_per_image_mean=float(np.mean(counts)), rois_per_step=n_rois,
+               path_algorithmic_bytes_per_step=roi_bytes + rest_bytes,
+               path_hbm_frac=(roi_bytes + rest_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+               roofline=dict(bound="hbm", kernel="roi_align_plane_kernel", achieved=roi_bytes / (ra_ms * 1e-3) / 1e9,
+                             peak=HBM_PEAK_GBPS, unit="GB/s", frac=roi_bytes / (ra_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             traffic=None, algorithmic_bytes_per_launch=roi_bytes, launch_ms=ra_ms,
+                             dominant_stage=max(stage_ms, key=stage_ms.get)))
+    return res, props, n_keep
 
 
 def main():
@@ -126,8 +216,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="images timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the NMS microbenchmarks")
+    ap.add_argument("--workload", choices=["realistic", "gaussian"], default="realistic")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="images timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workload and NMS microbenchmarks")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,39 +238,7 @@ def main():
     _lib.load()
     path = Path(dev)
     B = args.batch
-    cls, reg, feat = (t.to(dev) for t in make_batch(rank * B, B))
-    anchors = path.anchors(B, feat)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        path.step(anchors, cls, reg, feat)
-    barrier()
-    events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ev = []
-        props, n_keep, out, total = path.step(anchors, cls, reg, feat, ev)
-        events.append(ev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-stage device time from the events recorded inside the timed region
-    stage_ms = {}
-    for ev in events:
-        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
-            stage_ms.setdefault(n1, []).append(e0.elapsed_time(e1))
-    stage_ms = {k: float(np.mean(v)) for k, v in stage_ms.items()}
-    counts = n_keep.tolist()
-    n_rois = int(total.item())
+    main_res, props, n_keep = run_workload(path, dev, dist, rank, world, B, args.workload, args.steps, args.warmup)
 
     # final gather of per-image proposals over RCCL (outside the timed region)
     gather_ms = None
@@ -194,40 +253,38 @@ def main():
         gather_ms = (time.perf_counter() - g0) * 1e3
 
     extras = {}
-    if rank == 0 and not args.no_extras:
-        extras = nms_microbench(path, dev)
+    if not args.no_extras and world == 1:
+        other = "gaussian" if args.workload == "realistic" else "realistic"
+        sec, _, _ = run_workload(path, dev, None, 0, 1, B, other, max(5, args.steps // 5), 2)
+        sec.pop("roofline")
+        extras["secondary_workload"] = sec
+        extras.update(nms_microbench(path, dev))
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        # dominant kernel + its roofline (algorithmic bytes per launch / mean launch duration)
-        dominant = max(stage_ms, key=stage_ms.get)
-        roi_bytes = n_rois * C * 49 * 4 + B * C * FH * FW * 4 + n_rois * 20  # write + feature read + rois
-        ra_ms = stage_ms["roi_align"]
-        roofline = dict(bound="hbm", kernel="roi_align (incl. build_rois)", achieved=roi_bytes / (ra_ms * 1e-3) / 1e9,
-                        peak=HBM_PEAK_GBPS, unit="GB/s", traffic=None,
-                        algorithmic_bytes_per_launch=roi_bytes, launch_ms=ra_ms, dominant_stage=dominant)
-        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBPS
-        path_bytes = roi_bytes + B * (A * 4 + PRE_NMS * 8 + PRE_NMS * 32 + PRE_NMS * 20 + PRE_NMS * 20 + POST_NMS * 24)
+        desc = {"realistic": "proposal-realistic deltas (NMS keeps 2000/img)",
+                "gaussian": "SURVEY 8d Gaussian deltas (reference decode collapses them: ~270 kept/img)"}
         line = {
             "metric": "images/sec RPN proposal+RoIPool",
-            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] / SURVEY 8d config 2: batch %d x 600x1000 per GPU, 37x62 stride-16 "
-                                   "map, A=%d anchors/img, top-%d -> NMS %.1f -> <=%d, RoIAlign 7x7 C=%d, "
-                                   "reference (bug-compatible) decode" % (B, A, PRE_NMS, NMS_THR, POST_NMS, C),
+            "value": main_res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] / SURVEY 8d config 2: batch %d x 600x1000 per GPU, 37x62 "
+                                   "stride-16 map, A=%d anchors/img, top-%d -> NMS %.1f -> <=%d, RoIAlign 7x7 C=%d, "
+                                   "reference (bug-compatible) decode, %s"
+                                   % (B, A, PRE_NMS, NMS_THR, POST_NMS, C, desc[args.workload]),
                        "batch_per_gpu": B, "parallelism": "image-sharded x%d" % world,
-                       "proposals_per_image_mean": float(np.mean(counts)), "rois_per_step": n_rois},
-            "stage_ms": stage_ms,
-            "path_hbm_frac": path_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "roofline": roofline,
+                       "proposals_per_image_mean": main_res["proposals_per_image_mean"],
+                       "rois_per_step": main_res["rois_per_step"]},
+            "stage_ms": main_res["stage_ms"],
+            "path_algorithmic_bytes_per_step": main_res["path_algorithmic_bytes_per_step"],
+            "path_hbm_frac": main_res["path_hbm_frac"],
+            "roofline": main_res["roofline"],
             "gather_ms": gather_ms,
         }
         line.update(extras)
         if args.cpu_sample > 0 and world == 1:
             threads = min(os.cpu_count() or 1, 16)
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads, args.workload)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

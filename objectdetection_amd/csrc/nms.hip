@@ -164,7 +164,7 @@ nms_scan_kernel(const unsigned long long *__restrict__ mask, const int32_t *__re
 // instead of n^2/2 = 72 M at n = 12,000).  Same fp32 IoU expression, same threshold rule.
 #define NMS_LAZY_THREADS 1024
 #define NMS_LAZY_WAVES 16
-#define NMS_LAZY_LDS_LIMIT (128 * 1024)
+#define NMS_LAZY_LDS_LIMIT (120 * 1024)
 
 __device__ __forceinline__ float lane_bcast(float v, int src_lane)
 {
@@ -176,8 +176,11 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
                 float thr, int max_keep, int cap, int32_t *__restrict__ keep_out,
                 int32_t *__restrict__ n_keep_out)
 {
-    extern __shared__ float4 s_kbox[]; // [cap] kept boxes, followed by [cap] areas; cap = min(max_keep, max_n)
+    // dynamic LDS: [cap] kept boxes (float4), [cap] kept areas, [cap] kept positions
+    extern __shared__ float4 s_kbox[];
     float *s_karea = (float *)(s_kbox + cap);
+    int *s_kidx = (int *)(s_karea + cap);
+    __shared__ float4 s_cand[NMS_LAZY_THREADS]; // the next 16 blocks of candidates, staged per refill
     __shared__ unsigned long long s_row[64];
     __shared__ unsigned s_rem[2];
     __shared__ int s_nkeep;
@@ -187,90 +190,106 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const float4 *bx = boxes + (long long)b * max_n;
-    int32_t *keep = keep_out + (long long)b * max_keep;
     if (threadIdx.x == 0) {
         s_nkeep = 0;
         s_rem[0] = 0;
         s_rem[1] = 0;
     }
-    __syncthreads();
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 cb = lane < n ? bx[lane] : zero4;
-    for (int c = 0; c < Wn; ++c) {
-        const int nxt = (c + 1) * 64 + lane;
-        const float4 nb = nxt < n ? bx[nxt] : zero4; // prefetch the next block's candidates
-        const float carea = frcnn_area(cb.x, cb.y, cb.z, cb.w);
-        const int nk = s_nkeep;
-        // 1. pull
-        bool sup = false;
-        for (int r = wave; r < nk; r += NMS_LAZY_WAVES) {
-            float4 k = s_kbox[r];
-            float iou = frcnn_iou(k.x, k.y, k.z, k.w, s_karea[r], cb.x, cb.y, cb.z, cb.w, carea);
-            sup = sup || (iou > thr);
-        }
-        unsigned long long m = __ballot(sup);
-        if (lane == 0 && m != 0) {
-            atomicOr(&s_rem[0], (unsigned)m);
-            atomicOr(&s_rem[1], (unsigned)(m >> 32));
-        }
-        __syncthreads();
-        const int rows = min(64, n - c * 64);
-        const unsigned long long valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
-        unsigned long long rem =
-            uniform64((((unsigned long long)s_rem[1] << 32) | s_rem[0]) | ~valid);
-        const unsigned long long alive = ~rem;
-        // 2. diag rows of the alive candidates, spread over the waves
+    int nkeep_final = 0;
+    for (int c0 = 0; c0 < Wn; c0 += NMS_LAZY_WAVES) {
+        // refill: one coalesced 16-KB read serves the next 16 candidate blocks; no global memory
+        // operation is issued inside the per-block loop below, so its barriers are cheap
         {
-            unsigned long long rest = alive;
-            int a = 0;
-            while (rest != 0) {
-                int i = __ffsll((long long)rest) - 1;
-                rest &= rest - 1;
-                if ((a & (NMS_LAZY_WAVES - 1)) == wave) {
-                    float rx1 = lane_bcast(cb.x, i), ry1 = lane_bcast(cb.y, i);
-                    float rx2 = lane_bcast(cb.z, i), ry2 = lane_bcast(cb.w, i);
-                    float rarea = lane_bcast(carea, i);
-                    float iou = frcnn_iou(rx1, ry1, rx2, ry2, rarea, cb.x, cb.y, cb.z, cb.w, carea);
-                    unsigned long long w = __ballot(lane > i && iou > thr);
-                    if (lane == 0) s_row[i] = w;
+            int idx = c0 * 64 + threadIdx.x;
+            s_cand[threadIdx.x] = idx < n ? bx[idx] : zero4;
+        }
+        __syncthreads();
+        const int cend = min(Wn, c0 + NMS_LAZY_WAVES);
+        bool done = false;
+        for (int c = c0; c < cend; ++c) {
+            const float4 cb = s_cand[(c - c0) * 64 + lane];
+            const float carea = frcnn_area(cb.x, cb.y, cb.z, cb.w);
+            const int nk = s_nkeep;
+            // 1. pull
+            bool sup = false;
+            for (int r = wave; r < nk; r += NMS_LAZY_WAVES) {
+                float4 k = s_kbox[r];
+                float iou = frcnn_iou(k.x, k.y, k.z, k.w, s_karea[r], cb.x, cb.y, cb.z, cb.w, carea);
+                sup = sup || (iou > thr);
+            }
+            unsigned long long m = __ballot(sup);
+            if (lane == 0 && m != 0) {
+                atomicOr(&s_rem[0], (unsigned)m);
+                atomicOr(&s_rem[1], (unsigned)(m >> 32));
+            }
+            __syncthreads();
+            const int rows = min(64, n - c * 64);
+            const unsigned long long valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
+            unsigned long long rem =
+                uniform64((((unsigned long long)s_rem[1] << 32) | s_rem[0]) | ~valid);
+            const unsigned long long alive = ~rem;
+            // 2. diag rows of the alive candidates, spread over the waves
+            {
+                unsigned long long rest = alive;
+                int a = 0;
+                while (rest != 0) {
+                    int i = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    if ((a & (NMS_LAZY_WAVES - 1)) == wave) {
+                        float rx1 = lane_bcast(cb.x, i), ry1 = lane_bcast(cb.y, i);
+                        float rx2 = lane_bcast(cb.z, i), ry2 = lane_bcast(cb.w, i);
+                        float rarea = lane_bcast(carea, i);
+                        float iou = frcnn_iou(rx1, ry1, rx2, ry2, rarea, cb.x, cb.y, cb.z, cb.w, carea);
+                        unsigned long long w = __ballot(lane > i && iou > thr);
+                        if (lane == 0) s_row[i] = w;
+                    }
+                    ++a;
                 }
-                ++a;
+            }
+            __syncthreads();
+            // 3. resolve
+            if (wave == 0) {
+                const unsigned long long myrow = s_row[lane];
+                unsigned long long K = 0;
+                unsigned long long cand = alive;
+                int room = max_keep - nk;
+                while (cand != 0 && room > 0) {
+                    int i = __ffsll((long long)cand) - 1;
+                    K |= 1ull << i;
+                    --room;
+                    unsigned lo = __builtin_amdgcn_readlane((unsigned)myrow, i);
+                    unsigned hi = __builtin_amdgcn_readlane((unsigned)(myrow >> 32), i);
+                    rem |= ((unsigned long long)hi << 32) | lo;
+                    unsigned long long above = i >= 63 ? 0ull : (~0ull << (i + 1));
+                    cand = uniform64(~rem & above);
+                }
+                if ((K >> lane) & 1ull) {
+                    int pos = nk + __popcll(K & ((1ull << lane) - 1ull));
+                    s_kbox[pos] = cb;
+                    s_karea[pos] = carea;
+                    s_kidx[pos] = c * 64 + lane;
+                }
+                if (lane == 0) {
+                    s_nkeep = nk + __popcll(K);
+                    s_rem[0] = 0;
+                    s_rem[1] = 0;
+                }
+            }
+            __syncthreads();
+            nkeep_final = s_nkeep;
+            if (nkeep_final >= max_keep) {
+                done = true;
+                break;
             }
         }
-        __syncthreads();
-        // 3. resolve
-        if (wave == 0) {
-            const unsigned long long myrow = s_row[lane];
-            unsigned long long K = 0;
-            unsigned long long cand = alive;
-            int room = max_keep - nk;
-            while (cand != 0 && room > 0) {
-                int i = __ffsll((long long)cand) - 1;
-                K |= 1ull << i;
-                --room;
-                unsigned lo = __builtin_amdgcn_readlane((unsigned)myrow, i);
-                unsigned hi = __builtin_amdgcn_readlane((unsigned)(myrow >> 32), i);
-                rem |= ((unsigned long long)hi << 32) | lo;
-                unsigned long long above = i >= 63 ? 0ull : (~0ull << (i + 1));
-                cand = uniform64(~rem & above);
-            }
-            if ((K >> lane) & 1ull) {
-                int pos = nk + __popcll(K & ((1ull << lane) - 1ull));
-                s_kbox[pos] = cb;
-                s_karea[pos] = carea;
-                keep[pos] = c * 64 + lane;
-            }
-            if (lane == 0) {
-                s_nkeep = nk + __popcll(K);
-                s_rem[0] = 0;
-                s_rem[1] = 0;
-            }
-        }
-        __syncthreads();
-        if (s_nkeep >= max_keep) break;
-        cb = nb;
+        if (done) break;
     }
-    if (threadIdx.x == 0) n_keep_out[b] = s_nkeep;
+    __syncthreads();
+    nkeep_final = s_nkeep;
+    int32_t *keep = keep_out + (long long)b * max_keep;
+    for (int t = threadIdx.x; t < nkeep_final; t += NMS_LAZY_THREADS) keep[t] = s_kidx[t];
+    if (threadIdx.x == 0) n_keep_out[b] = nkeep_final;
 }
 
 extern "C" size_t frcnn_nms_workspace_bytes(int B, int max_n)
@@ -309,7 +328,7 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
     // Lazy path: the kept list (20 B per keep) must fit in LDS.  keep_out has max_keep columns,
     // but no more than max_n boxes can ever be kept.
     const int cap = max_keep < max_n ? max_keep : max_n;
-    const size_t lazy_lds = (size_t)cap * 20;
+    const size_t lazy_lds = (size_t)cap * 24;
     if (lazy_lds <= NMS_LAZY_LDS_LIMIT) {
         static size_t configured = 48 * 1024;
         if (lazy_lds > configured) {

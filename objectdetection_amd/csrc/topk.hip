@@ -267,6 +267,214 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
     }
 }
 
+// ---- register-resident variant ----------------------------------------------------------------
+// Same algorithm, but every phase works on registers: the image's keys are loaded ONCE (NR per
+// thread) for the four select passes and the compaction, and each sort pass loads a wave's whole
+// segment (KR rounds of 64) up front, ranks it from registers and scatters with fire-and-forget
+// stores.  The streaming kernel above pays one exposed memory latency per round of 64/1024
+// elements; this one pays one per pass.  Used when n <= NR*1024 and k <= KR*1024.
+__device__ __forceinline__ int2 block_excl_count2(int a, int b, int *wave_sums, int2 *total)
+{
+    // exclusive prefix counts of two flags at once, packed as (b << 16) | a (each <= 1024 per tile)
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    unsigned long long ma = __ballot(a != 0), mb = __ballot(b != 0);
+    unsigned long long lt = (1ull << lane) - 1ull;
+    int in_a = __popcll(ma & lt), in_b = __popcll(mb & lt);
+    if (lane == 0) wave_sums[wave] = (__popcll(mb) << 16) | __popcll(ma);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < TOPK_WAVES; ++w) {
+        int v = wave_sums[w];
+        if (w < wave) base += v;
+        tot += v;
+    }
+    __syncthreads();
+    *total = make_int2(tot & 0xFFFF, tot >> 16);
+    return make_int2((base & 0xFFFF) + in_a, (base >> 16) + in_b);
+}
+
+template <int NR, int KR>
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_reg_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ val_out,
+                int32_t *__restrict__ idx_out, uint32_t *__restrict__ ws)
+{
+    __shared__ unsigned s_hist[256];
+    __shared__ unsigned s_cnt[TOPK_WAVES][256];
+    __shared__ unsigned s_digit_base[256];
+    __shared__ int s_wave_sums[16];
+    __shared__ unsigned s_prefix, s_remaining;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float *sc = scores + (long long)b * n;
+    uint32_t *keyA = ws + (long long)b * 4 * k;
+    uint32_t *idxA = keyA + k;
+    uint32_t *keyB = idxA + k;
+    uint32_t *idxB = keyB + k;
+
+    // ---- 0. one pass over HBM: element i = r*1024 + tid
+    unsigned key[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        int i = r * TOPK_THREADS + tid;
+        key[r] = i < n ? frcnn_score_key(sc[i]) : 0u;
+    }
+
+    // ---- 1. radix select
+    unsigned prefix = 0, mask = 0, remaining = (unsigned)k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r * TOPK_THREADS < n) { // block-uniform
+                int i = r * TOPK_THREADS + tid;
+                bool act = i < n && (key[r] & mask) == prefix;
+                wave_hist_add(s_hist, (key[r] >> shift) & 255u, act);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            unsigned h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2],
+                     h3 = s_hist[4 * lane + 3];
+            unsigned sum = h0 + h1 + h2 + h3;
+            unsigned incl = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned t = __shfl_down(incl, o);
+                if (lane + o < 64) incl += t;
+            }
+            unsigned above = incl - sum;
+            unsigned s3 = above + h3, s2 = s3 + h2, s1 = s2 + h1, s0 = s1 + h0;
+            int d = -1;
+            unsigned cum = 0;
+            if (s3 >= remaining && above < remaining) { d = 4 * lane + 3; cum = above; }
+            else if (s2 >= remaining && s3 < remaining) { d = 4 * lane + 2; cum = s3; }
+            else if (s1 >= remaining && s2 < remaining) { d = 4 * lane + 1; cum = s2; }
+            else if (s0 >= remaining && s1 < remaining) { d = 4 * lane; cum = s1; }
+            if (d >= 0) {
+                s_prefix = prefix | ((unsigned)d << shift);
+                s_remaining = remaining - cum;
+            }
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        remaining = s_remaining;
+        mask |= 255u << shift;
+    }
+    const unsigned T = prefix;
+    const int need_eq = (int)remaining;
+
+    // ---- 2. index-ordered compaction: #selected before me = #gt before + min(#eq before, need_eq)
+    {
+        int gt_base = 0, eq_base = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r * TOPK_THREADS < n) {
+                int i = r * TOPK_THREADS + tid;
+                bool gt = i < n && key[r] > T;
+                bool eq = i < n && key[r] == T;
+                int2 tot;
+                int2 ex = block_excl_count2(gt, eq, s_wave_sums, &tot);
+                int eq_before = eq_base + ex.y;
+                if (gt || (eq && eq_before < need_eq)) {
+                    int pos = gt_base + ex.x + min(eq_before, need_eq);
+                    keyA[pos] = key[r];
+                    idxA[pos] = (uint32_t)i;
+                }
+                gt_base += tot.x;
+                eq_base += tot.y;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. stable LSD radix sort from registers
+    const int seg = ((k + TOPK_WAVES - 1) / TOPK_WAVES + 63) / 64 * 64;
+    const int seg_lo = min(wave * seg, k);
+    const int seg_hi = min(seg_lo + seg, k);
+    uint32_t *kin = keyA, *iin = idxA, *kout = keyB, *iout = idxB;
+    for (int shift = 0; shift < 32; shift += 8) {
+        unsigned kreg[KR], ireg[KR], rk[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            int e = seg_lo + r * 64 + lane;
+            bool act = e < seg_hi;
+            kreg[r] = act ? kin[e] : 0u;
+            ireg[r] = act ? iin[e] : 0u;
+        }
+        for (int t = tid; t < TOPK_WAVES * 256; t += TOPK_THREADS) (&s_cnt[0][0])[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            if (seg_lo + r * 64 < seg_hi) { // wave-uniform
+                bool act = seg_lo + r * 64 + lane < seg_hi;
+                unsigned dg = 255u - ((kreg[r] >> shift) & 255u);
+                unsigned long long peers = wave_match8(dg, act);
+                unsigned rank = (unsigned)__popcll(peers & ((1ull << lane) - 1ull));
+                unsigned cnt = (unsigned)__popcll(peers);
+                rk[r] = rank | (cnt << 8);
+                if (act && rank == 0) atomicAdd(&s_cnt[wave][dg], cnt);
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            unsigned run = 0;
+#pragma unroll
+            for (int w = 0; w < TOPK_WAVES; ++w) {
+                unsigned c = s_cnt[w][tid];
+                s_cnt[w][tid] = run;
+                run += c;
+            }
+            s_hist[tid] = run;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            unsigned v0 = s_hist[4 * lane], v1 = s_hist[4 * lane + 1], v2 = s_hist[4 * lane + 2],
+                     v3 = s_hist[4 * lane + 3];
+            unsigned sum = v0 + v1 + v2 + v3;
+            unsigned incl = sum;
+            for (int o = 1; o < 64; o <<= 1) {
+                unsigned t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            unsigned excl = incl - sum;
+            s_digit_base[4 * lane] = excl;
+            s_digit_base[4 * lane + 1] = excl + v0;
+            s_digit_base[4 * lane + 2] = excl + v0 + v1;
+            s_digit_base[4 * lane + 3] = excl + v0 + v1 + v2;
+        }
+        __syncthreads();
+        volatile unsigned *wcnt = s_cnt[wave];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            if (seg_lo + r * 64 < seg_hi) {
+                bool act = seg_lo + r * 64 + lane < seg_hi;
+                if (act) {
+                    unsigned dg = 255u - ((kreg[r] >> shift) & 255u);
+                    unsigned rank = rk[r] & 255u, cnt = rk[r] >> 8;
+                    unsigned off = wcnt[dg];
+                    unsigned pos = s_digit_base[dg] + off + rank;
+                    kout[pos] = kreg[r];
+                    iout[pos] = ireg[r];
+                    if (rank == 0) wcnt[dg] = off + cnt;
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *ti = iin; iin = iout; iout = ti;
+    }
+    for (int j = tid; j < k; j += TOPK_THREADS) {
+        unsigned idx = iin[j];
+        idx_out[(long long)b * k + j] = (int32_t)idx;
+        if (val_out) val_out[(long long)b * k + j] = sc[idx];
+    }
+}
+
 extern "C" size_t frcnn_topk_workspace_bytes(int B, int n, int k)
 {
     (void)n;
@@ -286,8 +494,18 @@ extern "C" int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, flo
                         frcnn_topk_workspace_bytes(B, n, k));
         return FRCNN_EWORKSPACE;
     }
-    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream, scores, n,
-                       k, val_out, idx_out, (uint32_t *)workspace);
+    if (n <= 8 * TOPK_THREADS && k <= 8 * TOPK_THREADS)
+        hipLaunchKernelGGL((topk_reg_kernel<8, 8>), dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream,
+                           scores, n, k, val_out, idx_out, (uint32_t *)workspace);
+    else if (n <= 24 * TOPK_THREADS && k <= 12 * TOPK_THREADS)
+        hipLaunchKernelGGL((topk_reg_kernel<24, 12>), dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream,
+                           scores, n, k, val_out, idx_out, (uint32_t *)workspace);
+    else if (n <= 32 * TOPK_THREADS && k <= 16 * TOPK_THREADS)
+        hipLaunchKernelGGL((topk_reg_kernel<32, 16>), dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream,
+                           scores, n, k, val_out, idx_out, (uint32_t *)workspace);
+    else
+        hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream, scores, n,
+                           k, val_out, idx_out, (uint32_t *)workspace);
     FRCNN_CHECK_LAUNCH("topk");
     return FRCNN_OK;
 }
