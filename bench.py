@@ -245,10 +245,9 @@ def main():
     if dist is not None:
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        all_props = [torch.empty_like(props) for _ in range(world)]
-        all_counts = [torch.empty_like(n_keep) for _ in range(world)]
-        dist.all_gather(all_props, props)
-        dist.all_gather(all_counts, n_keep)
+        from objectdetection_amd.sharding import gather_proposals
+        all_props, all_counts = gather_proposals(props, n_keep, dist)
+        assert all_props.shape[0] == world * B
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
 

@@ -5,6 +5,7 @@
 // The output (K, C, 7, 7) fp32 is 97 % of the hot path's HBM bytes: the kernels are
 // organised around writing it in long contiguous runs.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -265,6 +266,20 @@ __device__ __forceinline__ AxisSample axis_sample(float v, int n)
 
 #define RAP_THREADS 512
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc += w * f for four channels as two packed fp32 FMAs (v_pk_fma_f32: 2 lanes-worth per issue).
+__device__ __forceinline__ void pk_axpy4(f32x2 &lo, f32x2 &hi, float w, const float4 &f)
+{
+    f32x2 w2 = {w, w};
+    f32x2 a = {f.x, f.y}, c = {f.z, f.w};
+    lo = __builtin_elementwise_fma(w2, a, lo);
+    hi = __builtin_elementwise_fma(w2, c, hi);
+}
+
+// GT = channel groups (of 4) per chunk known at compile time (4 = a full 16-channel chunk), or 0
+// for the generic tail / narrow-chunk loop.
+template <int GT>
 __global__ void __launch_bounds__(RAP_THREADS)
 roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
                        const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
@@ -310,77 +325,87 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
     const int j0 = blockIdx.y * per;
     const int j1 = min(cnt, j0 + per);
     if (j0 >= j1) return;
-    const int items_per_roi = G * 49;
-    const int items = (j1 - j0) * items_per_roi;
+    // item = (RoI, bin): its 16 tap offsets and weights are computed once and reused for every
+    // channel group of the chunk
+    const int items = (j1 - j0) * 49;
     const float4 *pb = props + (long long)b * P;
     float *ob = out + ((long long)s_off * C + c0) * 49;
-    const float inv_items = 1.0f / (float)items_per_roi;
     for (int t = threadIdx.x; t < items; t += RAP_THREADS) {
-        // t / items_per_roi via a float reciprocal + fix-up (items < 2^23; host checks P*G*49)
-        int jl = (int)(((float)t + 0.5f) * inv_items);
-        int rem = t - jl * items_per_roi;
-        if (rem < 0) {
-            --jl;
-            rem += items_per_roi;
-        } else if (rem >= items_per_roi) {
-            ++jl;
-            rem -= items_per_roi;
-        }
-        int g = rem / 49;
-        int bin = rem - g * 49;
+        int jl = t / 49;
+        int bin = t - jl * 49;
         int ph = bin / 7, pw = bin - ph * 7;
         int j = j0 + jl;
         float4 box = pb[j];
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        bool write = true;
+        float *o = ob + (long long)j * C * 49 + bin;
+        bool pool = true;
         if (n_levels > 1) {
             int lv = map_level(box, k_min, k_max);
             bool none = lv < 0 || lv >= n_levels; // no level takes it: level 0's pass writes zeros
-            write = (lv == level) || (none && level == 0);
-            if (none) box = make_float4(0.0f, 0.0f, -1.0f, -1.0f), lv = -2;
-            if (lv != level) goto store;
-        }
-        {
-            float start_w = box.x * scale, start_h = box.y * scale;
-            float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
-            roi_w = roi_w > 1.0f ? roi_w : 1.0f;
-            roi_h = roi_h > 1.0f ? roi_h : 1.0f;
-            float bin_h = roi_h / 7.0f, bin_w = roi_w / 7.0f;
-            AxisSample ys[2], xs[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
-                xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
+            if (none && level == 0) {
+                for (int c = 0; c < nc; ++c) o[c * 49] = 0.0f;
             }
-            const float4 *pl = s_plane + g * HW;
-#pragma unroll
-            for (int iy = 0; iy < 2; ++iy) {
-#pragma unroll
-                for (int ix = 0; ix < 2; ++ix) {
-                    float4 f1 = pl[ys[iy].lo * W + xs[ix].lo];
-                    float4 f2 = pl[ys[iy].lo * W + xs[ix].hi];
-                    float4 f3 = pl[ys[iy].hi * W + xs[ix].lo];
-                    float4 f4 = pl[ys[iy].hi * W + xs[ix].hi];
-                    float w1 = ys[iy].wlo * xs[ix].wlo, w2 = ys[iy].wlo * xs[ix].whi;
-                    float w3 = ys[iy].whi * xs[ix].wlo, w4 = ys[iy].whi * xs[ix].whi;
-                    acc.x = fmaf(w4, f4.x, fmaf(w3, f3.x, fmaf(w2, f2.x, fmaf(w1, f1.x, acc.x))));
-                    acc.y = fmaf(w4, f4.y, fmaf(w3, f3.y, fmaf(w2, f2.y, fmaf(w1, f1.y, acc.y))));
-                    acc.z = fmaf(w4, f4.z, fmaf(w3, f3.z, fmaf(w2, f2.z, fmaf(w1, f1.z, acc.z))));
-                    acc.w = fmaf(w4, f4.w, fmaf(w3, f3.w, fmaf(w2, f2.w, fmaf(w1, f1.w, acc.w))));
-                }
-            }
-            acc.x *= 0.25f;
-            acc.y *= 0.25f;
-            acc.z *= 0.25f;
-            acc.w *= 0.25f;
+            pool = lv == level;
         }
-    store:
-        if (write) {
-            float *o = ob + ((long long)j * C + 4 * g) * 49 + bin;
-            o[0] = acc.x;
-            if (4 * g + 1 < nc) o[49] = acc.y;
-            if (4 * g + 2 < nc) o[98] = acc.z;
-            if (4 * g + 3 < nc) o[147] = acc.w;
+        if (!pool) continue;
+        float start_w = box.x * scale, start_h = box.y * scale;
+        float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
+        roi_w = roi_w > 1.0f ? roi_w : 1.0f;
+        roi_h = roi_h > 1.0f ? roi_h : 1.0f;
+        float bin_h = roi_h / 7.0f, bin_w = roi_w / 7.0f;
+        AxisSample ys[2], xs[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
+            xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
+        }
+        // row / column terms first (4 + 4), then the 16 tap offsets and weights are one add / one
+        // multiply each; the 1/4 of the 2x2 average is folded into the row weights (exact)
+        int ro[4] = {__mul24(ys[0].lo, W), __mul24(ys[0].hi, W), __mul24(ys[1].lo, W), __mul24(ys[1].hi, W)};
+        int co[4] = {xs[0].lo, xs[0].hi, xs[1].lo, xs[1].hi};
+        float rw[4] = {ys[0].wlo * 0.25f, ys[0].whi * 0.25f, ys[1].wlo * 0.25f, ys[1].whi * 0.25f};
+        float cw[4] = {xs[0].wlo, xs[0].whi, xs[1].wlo, xs[1].whi};
+        int off[16];
+        float wt[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                off[r * 4 + c] = ro[r] + co[c];
+                wt[r * 4 + c] = rw[r] * cw[c];
+            }
+        }
+        if (GT == 4) {
+            // groups 0,1 and 2,3 share a base: the second of each pair is an immediate LDS offset
+            const float4 *pl0 = s_plane;
+            const float4 *pl2 = s_plane + 2 * HW;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 *pl = (g < 2 ? pl0 : pl2) + (g & 1) * HW;
+                f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+                float4 tap[16]; // all 16 LDS reads in flight before the first FMA consumes one
+#pragma unroll
+                for (int q = 0; q < 16; ++q) tap[q] = pl[off[q]];
+                __builtin_amdgcn_sched_barrier(0); // hipcc otherwise issues the reads two at a time
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], tap[q]);
+                float *og = o + (4 * g) * 49;
+                og[0] = lo.x;
+                og[49] = lo.y;
+                og[98] = hi.x;
+                og[147] = hi.y;
+            }
+        } else {
+            for (int g = 0; g < G; ++g) {
+                const float4 *pl = s_plane + g * HW;
+                f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
+                float *og = o + (4 * g) * 49;
+                og[0] = lo.x;
+                if (4 * g + 1 < nc) og[49] = lo.y;
+                if (4 * g + 2 < nc) og[98] = hi.x;
+                if (4 * g + 3 < nc) og[147] = hi.y;
+            }
         }
     }
 }
@@ -484,7 +509,7 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
                   "roi_align_batched: pooled_h*pooled_w*sampling_ratio^2 exceeds %d", RA_MAX_SAMPLES);
     const long long plane_bytes = (long long)H * W * 4;
     if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && plane_bytes * 4 <= RAP_LDS_BUDGET &&
-        (long long)P * 4 * 49 < (1ll << 23)) {
+        (long long)P * 49 < (1ll << 30)) {
         int CC = 16;
         while (CC > 4 && plane_bytes * CC > RAP_LDS_BUDGET) CC >>= 1;
         if (CC > C) CC = (C + 3) / 4 * 4;
@@ -494,17 +519,25 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         if (splits < 1) splits = 1;
         if (splits > 16) splits = 16;
         size_t lds = (size_t)plane_bytes * (size_t)CC;
-        static size_t configured = 0;
+        static size_t configured4 = 0, configured0 = 0;
+        const bool full = (CC == 16) && (C % 16 == 0);
+        size_t &configured = full ? configured4 : configured0;
         if (lds > configured) {
-            hipError_t e = hipFuncSetAttribute((const void *)roi_align_plane_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(
+                full ? (const void *)roi_align_plane_kernel<4> : (const void *)roi_align_plane_kernel<0>,
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
                           hipGetErrorString(e));
             configured = lds;
         }
-        hipLaunchKernelGGL(roi_align_plane_kernel, dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
-                           (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
-                           spatial_scale, level, n_levels, k_min, k_max, out, total_out);
+        if (full)
+            hipLaunchKernelGGL(roi_align_plane_kernel<4>, dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
+                               (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
+                               spatial_scale, level, n_levels, k_min, k_max, out, total_out);
+        else
+            hipLaunchKernelGGL(roi_align_plane_kernel<0>, dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
+                               (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
+                               spatial_scale, level, n_levels, k_min, k_max, out, total_out);
         FRCNN_CHECK_LAUNCH("roi_align_plane");
         return FRCNN_OK;
     }

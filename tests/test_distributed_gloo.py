@@ -1,0 +1,71 @@
+"""world_size-2 gloo rehearsal of the N>1 path: images are sharded by rank, each rank produces its
+own proposals (here with the CPU oracle standing in for the GPU path), and the final gather
+reassembles the batch in global image order -- identical to a single-process run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_IMAGES, P = 5, 40
+INFO_HW, FSZ = (96, 160), [(6, 10)]
+PARAMS = dict(num_pre_nms=300, num_post_nms=P, nms_threshold=0.7, proposal_min_size=1e-3)
+
+
+def image_inputs(index):
+    rng = np.random.default_rng(1234 + index)
+    n = 6 * 10 * 9
+    cls = (((rng.permutation(n).astype(np.float32) / np.float32(n)) - np.float32(0.5)) * np.float32(8))
+    cls = cls.reshape(6, 10, 9).transpose(2, 0, 1)[None]
+    reg = rng.standard_normal((1, 36, 6, 10)).astype(np.float32) * np.float32(0.3)
+    return np.ascontiguousarray(cls), reg
+
+
+def proposals_for(indices):
+    from oracle import oracle as orc
+    props = np.zeros((len(indices), P, 4), np.float32)
+    counts = np.zeros((len(indices),), np.int32)
+    for i, idx in enumerate(indices):
+        cls, reg = image_inputs(idx)
+        p = orc.rpn_proposals((1,) + INFO_HW, [cls], [reg], PARAMS)[0]
+        props[i, :len(p)] = p
+        counts[i] = len(p)
+    return props, counts
+
+
+def worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from objectdetection_amd.sharding import gather_proposals, shard_range
+    lo, hi = shard_range(rank, world, N_IMAGES)
+    props, counts = proposals_for(range(lo, hi))
+    all_p, all_c = gather_proposals(torch.from_numpy(props), torch.from_numpy(counts), dist)
+    # timing protocol of bench.py: barrier + max over ranks
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), p=all_p.numpy(), c=all_c.numpy(), t=t.numpy(), span=[lo, hi])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather(tmp_path, oracle):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref_p, ref_c = proposals_for(range(N_IMAGES))
+    spans = []
+    for r in range(2):
+        z = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.array_equal(z["c"], ref_c) and np.array_equal(z["p"], ref_p)
+        assert float(z["t"][0]) == 2.0
+        spans.append(tuple(z["span"]))
+    assert spans == [(0, 3), (3, 5)]
+    assert ref_c.sum() > 0
