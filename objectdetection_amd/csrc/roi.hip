@@ -264,11 +264,11 @@ __device__ __forceinline__ AxisSample axis_sample(float v, int n)
     return a;
 }
 
-#define RAP_THREADS 512
+#define RAP_THREADS 1024
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// acc += w * f for four channels as two packed fp32 FMAs (v_pk_fma_f32: 2 lanes-worth per issue).
+// acc += w * f for four channels as two packed fp32 FMAs (v_pk_fma_f32).
 __device__ __forceinline__ void pk_axpy4(f32x2 &lo, f32x2 &hi, float w, const float4 &f)
 {
     f32x2 w2 = {w, w};
@@ -277,23 +277,40 @@ __device__ __forceinline__ void pk_axpy4(f32x2 &lo, f32x2 &hi, float w, const fl
     hi = __builtin_elementwise_fma(w2, c, hi);
 }
 
-// GT = channel groups (of 4) per chunk known at compile time (4 = a full 16-channel chunk), or 0
-// for the generic tail / narrow-chunk loop.
-template <int GT>
+// LDS image of a chunk: index (in float4 = 4-channel pixels) = (y * G + g) * WS + (x ^ swz(y)),
+// WS = W rounded up to 16.  The G channel groups of a row sit WS pixels apart, so with a
+// compile-time WS the per-group tap address is an IMMEDIATE ds_read offset (g * WS * 16 bytes) and
+// the 16 tap addresses of an item are computed once for all its channels.  A pixel is one 16-byte
+// slot, 16 slots span the 64 banks, and every row starts on a multiple of 16 slots, so the slot of
+// (y, x) is (x ^ swz(y)) & 15; the 4-bit bit reversal swz(y) keeps bins of neighbouring rows that
+// share a column off the same banks.
+__device__ __forceinline__ int rap_swz(int y)
+{
+    return ((y & 1) << 3) | ((y & 2) << 1) | ((y & 4) >> 1) | ((y & 8) >> 3);
+}
+
+// The profile that shaped this kernel (rocprofv3 PMC, MI355X): it is bound by vector-instruction
+// ISSUE (about 5 cycles per wave instruction, 65 % of all SIMD cycles issuing), not by LDS
+// bandwidth, HBM or the store path -- so everything that is not one of the 32 packed FMAs per
+// (item, channel group) is hoisted out of the group loop or folded into an immediate.
+// GT  = channel groups per chunk known at compile time (4 = a full 16-channel chunk) or 0.
+// WST = compile-time LDS row stride in pixels (64 covers W <= 64) or 0 for a runtime stride.
+template <int GT, int WST>
 __global__ void __launch_bounds__(RAP_THREADS)
 roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
                        const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
                        int CC, float scale, int level, int n_levels, int k_min, int k_max,
                        float *__restrict__ out, int32_t *__restrict__ total_out)
 {
-    extern __shared__ float4 s_plane[]; // [G][H*W]
+    extern __shared__ float4 s_plane[];
     __shared__ int s_off, s_cnt;
     const int b = blockIdx.z;
     const int B = gridDim.z;
     const int c0 = blockIdx.x * CC;
     const int nc = min(CC, C - c0);
-    const int G = (nc + 3) >> 2;
+    const int G = GT ? GT : (nc + 3) >> 2;
     const int HW = H * W;
+    const int WS = WST ? WST : (W + 15) & ~15;
     if (threadIdx.x == 0) {
         int off = 0, tot = 0;
         for (int i = 0; i < B; ++i) {
@@ -311,13 +328,15 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
     for (int t = threadIdx.x; t < G * HW; t += RAP_THREADS) {
         int g = t / HW;
         int p = t - g * HW;
+        int y = p / W;
+        int x = p - y * W;
         const float *f = fb + (long long)(4 * g) * HW + p;
         float4 v;
         v.x = f[0];
         v.y = 4 * g + 1 < nc ? f[HW] : 0.0f;
         v.z = 4 * g + 2 < nc ? f[2 * HW] : 0.0f;
         v.w = 4 * g + 3 < nc ? f[3 * HW] : 0.0f;
-        s_plane[t] = v;
+        s_plane[(y * G + g) * WS + (x ^ rap_swz(y))] = v;
     }
     __syncthreads();
     const int cnt = s_cnt;
@@ -325,9 +344,10 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
     const int j0 = blockIdx.y * per;
     const int j1 = min(cnt, j0 + per);
     if (j0 >= j1) return;
-    // item = (RoI, bin): its 16 tap offsets and weights are computed once and reused for every
+    // item = (RoI, bin): its 16 tap addresses and weights are computed once and reused for every
     // channel group of the chunk
     const int items = (j1 - j0) * 49;
+    const int row_stride = G * WS;
     const float4 *pb = props + (long long)b * P;
     float *ob = out + ((long long)s_off * C + c0) * 49;
     for (int t = threadIdx.x; t < items; t += RAP_THREADS) {
@@ -358,37 +378,32 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
             ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
             xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
         }
-        // row / column terms first (4 + 4), then the 16 tap offsets and weights are one add / one
-        // multiply each; the 1/4 of the 2x2 average is folded into the row weights (exact)
-        int ro[4] = {__mul24(ys[0].lo, W), __mul24(ys[0].hi, W), __mul24(ys[1].lo, W), __mul24(ys[1].hi, W)};
-        int co[4] = {xs[0].lo, xs[0].hi, xs[1].lo, xs[1].hi};
-        float rw[4] = {ys[0].wlo * 0.25f, ys[0].whi * 0.25f, ys[1].wlo * 0.25f, ys[1].whi * 0.25f};
-        float cw[4] = {xs[0].wlo, xs[0].whi, xs[1].wlo, xs[1].whi};
+        // 4 row terms + 4 column terms, then one (xor, add) and one multiply per tap; the 1/4 of
+        // the 2x2 average is folded into the row weights (exact: power of two)
+        const int yr[4] = {ys[0].lo, ys[0].hi, ys[1].lo, ys[1].hi};
+        const int xc[4] = {xs[0].lo, xs[0].hi, xs[1].lo, xs[1].hi};
+        const float rw[4] = {ys[0].wlo * 0.25f, ys[0].whi * 0.25f, ys[1].wlo * 0.25f, ys[1].whi * 0.25f};
+        const float cw[4] = {xs[0].wlo, xs[0].whi, xs[1].wlo, xs[1].whi};
         int off[16];
         float wt[16];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            const int rb = __mul24(yr[r], row_stride);
+            const int sw = rap_swz(yr[r]);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                off[r * 4 + c] = ro[r] + co[c];
+                off[r * 4 + c] = (xc[c] ^ sw) + rb;
                 wt[r * 4 + c] = rw[r] * cw[c];
             }
         }
-        if (GT == 4) {
-            // groups 0,1 and 2,3 share a base: the second of each pair is an immediate LDS offset
-            const float4 *pl0 = s_plane;
-            const float4 *pl2 = s_plane + 2 * HW;
+        if (GT) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 *pl = (g < 2 ? pl0 : pl2) + (g & 1) * HW;
+            for (int g = 0; g < (GT ? GT : 1); ++g) {
+                const float4 *pl = s_plane + g * WS; // immediate offset when WST != 0
                 f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
-                float4 tap[16]; // all 16 LDS reads in flight before the first FMA consumes one
 #pragma unroll
-                for (int q = 0; q < 16; ++q) tap[q] = pl[off[q]];
-                __builtin_amdgcn_sched_barrier(0); // hipcc otherwise issues the reads two at a time
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], tap[q]);
-                float *og = o + (4 * g) * 49;
+                for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
+                float *og = o + (4 * g) * 49; // immediate store offsets
                 og[0] = lo.x;
                 og[49] = lo.y;
                 og[98] = hi.x;
@@ -396,7 +411,7 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
             }
         } else {
             for (int g = 0; g < G; ++g) {
-                const float4 *pl = s_plane + g * HW;
+                const float4 *pl = s_plane + g * WS;
                 f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
 #pragma unroll
                 for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
@@ -507,9 +522,10 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
     FRCNN_REQUIRE(sampling_ratio >= 1, "roi_align_batched: sampling_ratio must be >= 1 (got %d)", sampling_ratio);
     FRCNN_REQUIRE((long long)pooled_h * pooled_w * sampling_ratio * sampling_ratio <= RA_MAX_SAMPLES,
                   "roi_align_batched: pooled_h*pooled_w*sampling_ratio^2 exceeds %d", RA_MAX_SAMPLES);
-    const long long plane_bytes = (long long)H * W * 4;
+    const int WS = (W + 15) & ~15;                       // LDS row stride of the plane kernel
+    const long long plane_bytes = (long long)H * WS * 4; // LDS bytes per channel
     if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && plane_bytes * 4 <= RAP_LDS_BUDGET &&
-        (long long)P * 49 < (1ll << 30)) {
+        (long long)P * 49 < (1ll << 30) && (long long)H * WS * 4 < (1 << 23)) {
         int CC = 16;
         while (CC > 4 && plane_bytes * CC > RAP_LDS_BUDGET) CC >>= 1;
         if (CC > C) CC = (C + 3) / 4 * 4;
@@ -519,23 +535,24 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         if (splits < 1) splits = 1;
         if (splits > 16) splits = 16;
         size_t lds = (size_t)plane_bytes * (size_t)CC;
+        // fast instantiation: full 16-channel chunks on a map at most 64 pixels wide
+        const bool full = (CC == 16) && (C % 16 == 0) && WS == 64;
         static size_t configured4 = 0, configured0 = 0;
-        const bool full = (CC == 16) && (C % 16 == 0);
         size_t &configured = full ? configured4 : configured0;
         if (lds > configured) {
             hipError_t e = hipFuncSetAttribute(
-                full ? (const void *)roi_align_plane_kernel<4> : (const void *)roi_align_plane_kernel<0>,
+                full ? (const void *)roi_align_plane_kernel<4, 64> : (const void *)roi_align_plane_kernel<0, 0>,
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
                           hipGetErrorString(e));
             configured = lds;
         }
         if (full)
-            hipLaunchKernelGGL(roi_align_plane_kernel<4>, dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
+            hipLaunchKernelGGL((roi_align_plane_kernel<4, 64>), dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
                                (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
                                spatial_scale, level, n_levels, k_min, k_max, out, total_out);
         else
-            hipLaunchKernelGGL(roi_align_plane_kernel<0>, dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
+            hipLaunchKernelGGL((roi_align_plane_kernel<0, 0>), dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
                                (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
                                spatial_scale, level, n_levels, k_min, k_max, out, total_out);
         FRCNN_CHECK_LAUNCH("roi_align_plane");
