@@ -1,72 +1,26 @@
 // nms.hip -- K4: batched greedy NMS (torchvision.ops.nms semantics; call sites RPN/rpn.py:84 and
 // ROIHead/roi_head.py:215).
 //
-// Two kernels, both batched over images:
-//   nms_mask_kernel : 64x64 suppression tiles.  Lane = column box, the 64 row boxes of the tile
-//                     are broadcast from LDS; `iou > thr` is evaluated for 64 columns at once and
-//                     the wave's compare mask (the ballot) IS the 64-bit suppression word of the
-//                     row.  Only the upper triangle (column block >= row block) is computed.
-//                     Tiles are stored tile-major, [row block][col block][row in block], so every
-//                     wave writes one coalesced 512-B line set.
-//   nms_scan_kernel : one workgroup per image walks the row blocks in order; wave 0 resolves the
-//                     64 candidates of a block against the running `removed` word (scalar loop over
-//                     surviving candidates only: ffs / readlane / or), then all 16 waves fold the
-//                     kept rows' tiles into `removed` for the later column blocks with a wave-wide
-//                     OR reduction.  Stops as soon as max_keep boxes are kept.
+// Greedy NMS only ever consults the IoU of a candidate with the boxes KEPT before it, so neither
+// path below builds the n x n suppression matrix:
 //
-// IoU is the reference's fp32 expression with IEEE division; the decision `(double)iou > thr` is
-// made with the float threshold t = RD(thr) (largest fp32 <= thr), which is equivalent for every
-// fp32 iou.  NaN never suppresses.
+//   lazy kernel  (n <= 2048): one workgroup per image, kept list in LDS, 64 candidates per step:
+//                pull against the kept list -> intra-block rows of the survivors -> scalar resolve.
+//   round kernels (larger n): candidates are taken 1024 at a time.  Per round, kernel PM spreads
+//                over the whole chip (a) the PULL of the round's 1024 candidates against every box
+//                kept so far (wave = 64 candidates x a slice of the kept rows, ballot -> atomicOr)
+//                and (b) the 136 upper-triangular 64x64 suppression TILES of the round's own
+//                candidates; kernel L (one workgroup per image) then resolves the 16 blocks in
+//                order from LDS: scalar ffs / readlane / or over survivors, wave-wide OR folds of
+//                the kept rows' tiles.  Rounds after max_keep is reached exit at once.
+//
+// In both, `iou > thr` for 64 columns is one compare whose lane mask (the ballot) IS the 64-bit
+// suppression word.  IoU is the reference's fp32 expression with IEEE division; the decision
+// `(double)iou > thr` is made with the float threshold t = RD(thr) (largest fp32 <= thr), which is
+// equivalent for every fp32 iou.  NaN never suppresses.
 #include <math.h>
 
 #include "common.h"
-
-#define NMS_SCAN_THREADS 1024
-#define NMS_SCAN_WAVES 16
-#define NMS_COL_WAVES 4 // waves per mask block; each wave owns one column block at a time
-
-__global__ void __launch_bounds__(256)
-nms_mask_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
-                int max_n, int W, float thr, unsigned long long *__restrict__ mask)
-{
-    __shared__ float4 s_row[64];
-    __shared__ float s_row_area[64];
-    const int b = blockIdx.z;
-    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
-    const int rb = blockIdx.x;
-    if (rb * 64 >= n) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int Wn = (n + 63) >> 6;
-    const float4 *bx = boxes + (long long)b * max_n;
-    if (threadIdx.x < 64) {
-        int r = rb * 64 + threadIdx.x;
-        float4 v = r < n ? bx[r] : make_float4(0, 0, 0, 0);
-        s_row[threadIdx.x] = v;
-        s_row_area[threadIdx.x] = frcnn_area(v.x, v.y, v.z, v.w);
-    }
-    __syncthreads();
-    unsigned long long *mimg = mask + (long long)b * W * W * 64;
-    const int stride = gridDim.y * NMS_COL_WAVES;
-    for (int cb = rb + blockIdx.y * NMS_COL_WAVES + wave; cb < Wn; cb += stride) {
-        int c = cb * 64 + lane;
-        bool cvalid = c < n;
-        float4 cbx = cvalid ? bx[c] : make_float4(0, 0, 0, 0);
-        float carea = frcnn_area(cbx.x, cbx.y, cbx.z, cbx.w);
-        unsigned long long word = 0;
-        const bool diag = cb == rb;
-#pragma unroll 8
-        for (int i = 0; i < 64; ++i) {
-            float4 r = s_row[i];
-            float iou = frcnn_iou(r.x, r.y, r.z, r.w, s_row_area[i], cbx.x, cbx.y, cbx.z, cbx.w,
-                                  carea);
-            bool sup = cvalid && (iou > thr) && (!diag || lane > i);
-            unsigned long long m = __ballot(sup);
-            if (lane == i) word = m;
-        }
-        mimg[((long long)rb * W + cb) * 64 + lane] = word;
-    }
-}
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v)
 {
@@ -86,70 +40,6 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ void __launch_bounds__(NMS_SCAN_THREADS)
-nms_scan_kernel(const unsigned long long *__restrict__ mask, const int32_t *__restrict__ n_per_image,
-                int max_n, int W, int max_keep, int32_t *__restrict__ keep_out,
-                int32_t *__restrict__ n_keep_out)
-{
-    extern __shared__ unsigned long long s_removed[]; // W words
-    __shared__ unsigned long long s_keep;
-    __shared__ int s_nkeep;
-    const int b = blockIdx.x;
-    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
-    const int Wn = (n + 63) >> 6;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const unsigned long long *mimg = mask + (long long)b * W * W * 64;
-    int32_t *keep = keep_out + (long long)b * max_keep;
-    for (int t = threadIdx.x; t < Wn; t += NMS_SCAN_THREADS) s_removed[t] = 0;
-    if (threadIdx.x == 0) s_nkeep = 0;
-    __syncthreads();
-    for (int c = 0; c < Wn; ++c) {
-        if (wave == 0) {
-            int nkeep = s_nkeep;
-            unsigned long long d = mimg[((long long)c * W + c) * 64 + lane]; // diagonal tile
-            int rows = min(64, n - c * 64);
-            unsigned long long valid = rows >= 64 ? ~0ull : ((1ull << rows) - 1ull);
-            unsigned long long rem = uniform64(s_removed[c]);
-            unsigned long long K = 0;
-            unsigned long long cand = ~rem & valid;
-            int room = max_keep - nkeep;
-            while (cand != 0 && room > 0) {
-                int bit = __ffsll((long long)cand) - 1;
-                K |= 1ull << bit;
-                --room;
-                unsigned lo = __builtin_amdgcn_readlane((unsigned)d, bit);
-                unsigned hi = __builtin_amdgcn_readlane((unsigned)(d >> 32), bit);
-                rem |= ((unsigned long long)hi << 32) | lo;
-                unsigned long long above = bit >= 63 ? 0ull : (~0ull << (bit + 1));
-                cand = uniform64(~rem & valid & above);
-            }
-            if ((K >> lane) & 1ull) {
-                int pos = nkeep + __popcll(K & ((1ull << lane) - 1ull));
-                keep[pos] = c * 64 + lane;
-            }
-            if (lane == 0) {
-                s_keep = K;
-                s_nkeep = nkeep + __popcll(K);
-            }
-        }
-        __syncthreads();
-        const unsigned long long K = s_keep;
-        const bool done = s_nkeep >= max_keep;
-        if (!done && K != 0) {
-            for (int cb = c + 1 + wave; cb < Wn; cb += NMS_SCAN_WAVES) {
-                unsigned long long v = mimg[((long long)c * W + cb) * 64 + lane];
-                v = ((K >> lane) & 1ull) ? v : 0ull;
-                v = wave_or64(v);
-                if (lane == 0) s_removed[cb] |= v;
-            }
-        }
-        __syncthreads();
-        if (done) break;
-    }
-    if (threadIdx.x == 0) n_keep_out[b] = s_nkeep;
-}
-
 // ---- lazy ("pull") NMS ------------------------------------------------------------------------
 // One 1024-thread workgroup per image, no suppression matrix at all.  The kept boxes live in LDS.
 // For each block of 64 candidates (lane = candidate):
@@ -164,7 +54,6 @@ nms_scan_kernel(const unsigned long long *__restrict__ mask, const int32_t *__re
 // instead of n^2/2 = 72 M at n = 12,000).  Same fp32 IoU expression, same threshold rule.
 #define NMS_LAZY_THREADS 1024
 #define NMS_LAZY_WAVES 16
-#define NMS_LAZY_LDS_LIMIT (120 * 1024)
 
 __device__ __forceinline__ float lane_bcast(float v, int src_lane)
 {
@@ -292,11 +181,219 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
     if (threadIdx.x == 0) n_keep_out[b] = nkeep_final;
 }
 
+// ---- round-based NMS --------------------------------------------------------------------------
+#define NMS_RS 1024                       // candidates per round
+#define NMS_RC (NMS_RS / 64)              // 64-candidate blocks per round (16)
+#define NMS_RT (NMS_RC * (NMS_RC + 1) / 2) // upper-triangular tiles per round (136)
+#define NMS_TILE_GROUPS ((NMS_RT + NMS_RC * 4 - 1) / (NMS_RC * 4)) // grid.y slices of tile waves (3)
+
+// Per-image workspace of the round path (all offsets 16-byte aligned).
+struct NmsWs {
+    float4 *kbox;              // [cap] kept boxes, in keep order
+    float *karea;              // [cap]
+    unsigned long long *tiles; // [NMS_RT][64] this round's suppression tiles, tile-major
+    unsigned long long *sup;   // [NMS_RC] this round's pull result (zero between rounds)
+    int *nkeep;                // [1]
+};
+
+static size_t nms_ws_stride(int cap)
+{
+    return frcnn_align_up((size_t)cap * 16, 256) + frcnn_align_up((size_t)cap * 4, 256) +
+           (size_t)NMS_RT * 64 * 8 + 256 /* sup */ + 256 /* nkeep */;
+}
+
+__device__ __forceinline__ NmsWs nms_ws(char *base, size_t stride, int b, int cap)
+{
+    char *p = base + (size_t)b * stride;
+    NmsWs w;
+    w.kbox = (float4 *)p;
+    p += ((size_t)cap * 16 + 255) / 256 * 256;
+    w.karea = (float *)p;
+    p += ((size_t)cap * 4 + 255) / 256 * 256;
+    w.tiles = (unsigned long long *)p;
+    p += (size_t)NMS_RT * 64 * 8;
+    w.sup = (unsigned long long *)p;
+    p += 256;
+    w.nkeep = (int *)p;
+    return w;
+}
+
+// tile id -> (row block, col block), row-major over the upper triangle
+__device__ __forceinline__ void nms_tile_rc(int id, int *rb, int *cb)
+{
+    int r = 0, left = id;
+    while (left >= NMS_RC - r) {
+        left -= NMS_RC - r;
+        ++r;
+    }
+    *rb = r;
+    *cb = r + left;
+}
+
+__device__ __forceinline__ int nms_tile_id(int rb, int cb)
+{
+    return rb * NMS_RC - rb * (rb - 1) / 2 + (cb - rb);
+}
+
+// Kernel PM of a round.  grid = (16 candidate blocks, RSPLIT pull slices + tile slices, B).
+__global__ void __launch_bounds__(256)
+nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
+                    int max_n, float thr, int max_keep, int cap, int round, int rsplit, char *ws,
+                    size_t ws_stride)
+{
+    const int b = blockIdx.z;
+    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
+    const int base = round * NMS_RS;
+    if (base >= n) return;
+    const NmsWs w = nms_ws(ws, ws_stride, b, cap);
+    const int nk = *w.nkeep;
+    if (nk >= max_keep) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float4 *bx = boxes + (long long)b * max_n;
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if ((int)blockIdx.y < rsplit) {
+        // ---- pull: 64 candidates (lanes) x kept rows wave*..; the kept box is wave-uniform
+        const int c = blockIdx.x;
+        const int idx = base + c * 64 + lane;
+        if (base + c * 64 >= n || nk == 0) return;
+        const float4 cb = idx < n ? bx[idx] : zero4;
+        const float carea = frcnn_area(cb.x, cb.y, cb.z, cb.w);
+        bool sup = false;
+        const int step = rsplit * 4;
+        for (int r = blockIdx.y * 4 + wave; r < nk; r += step) {
+            const float4 k = w.kbox[r];
+            const float iou = frcnn_iou(k.x, k.y, k.z, k.w, w.karea[r], cb.x, cb.y, cb.z, cb.w, carea);
+            sup = sup || (iou > thr);
+        }
+        const unsigned long long m = __ballot(sup);
+        if (lane == 0 && m != 0) atomicOr(&w.sup[c], m);
+    } else {
+        // ---- tiles: wave = one 64x64 tile of the round's own candidates
+        const int id = (((int)blockIdx.y - rsplit) * NMS_RC + blockIdx.x) * 4 + wave;
+        if (id >= NMS_RT) return;
+        int rb, cbk;
+        nms_tile_rc(id, &rb, &cbk);
+        if (base + cbk * 64 >= n) return;
+        const int ri = base + rb * 64 + lane, ci = base + cbk * 64 + lane;
+        const float4 rbx = ri < n ? bx[ri] : zero4;
+        const float4 cbx = ci < n ? bx[ci] : zero4;
+        const float rarea = frcnn_area(rbx.x, rbx.y, rbx.z, rbx.w);
+        const float carea = frcnn_area(cbx.x, cbx.y, cbx.z, cbx.w);
+        const bool diag = rb == cbk;
+        unsigned long long word = 0;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {
+            const float x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.x), i));
+            const float y1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.y), i));
+            const float x2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.z), i));
+            const float y2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.w), i));
+            const float ra = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rarea), i));
+            const float iou = frcnn_iou(x1, y1, x2, y2, ra, cbx.x, cbx.y, cbx.z, cbx.w, carea);
+            const unsigned long long m = __ballot(ci < n && iou > thr && (!diag || lane > i));
+            if (lane == i) word = m;
+        }
+        w.tiles[(long long)id * 64 + lane] = word;
+    }
+}
+
+// Kernel L of a round: one workgroup per image resolves the round's 16 candidate blocks in order.
+__global__ void __launch_bounds__(1024)
+nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
+                      int max_n, int max_keep, int cap, int round, char *ws, size_t ws_stride,
+                      int32_t *__restrict__ keep_out, int32_t *__restrict__ n_keep_out)
+{
+    __shared__ unsigned long long s_tiles[NMS_RT * 64];
+    __shared__ unsigned long long s_removed[NMS_RC];
+    __shared__ unsigned long long s_K[NMS_RC];
+    __shared__ int s_nkeep;
+    const int b = blockIdx.x;
+    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
+    const int base = round * NMS_RS;
+    const NmsWs w = nms_ws(ws, ws_stride, b, cap);
+    const int nk0 = *w.nkeep;
+    if (base >= n || nk0 >= max_keep) {
+        if (threadIdx.x == 0) n_keep_out[b] = nk0;
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cnt = min(NMS_RS, n - base);
+    const int nC = (cnt + 63) >> 6;
+    for (int t = threadIdx.x; t < NMS_RT * 64; t += 1024) s_tiles[t] = w.tiles[t];
+    if (threadIdx.x < NMS_RC) {
+        const int c = threadIdx.x;
+        const int rows = min(64, cnt - c * 64);
+        const unsigned long long valid = rows >= 64 ? ~0ull : (rows <= 0 ? 0ull : ((1ull << rows) - 1ull));
+        s_removed[c] = w.sup[c] | ~valid;
+        s_K[c] = 0;
+        w.sup[c] = 0; // ready for the next round's atomicOr
+    }
+    if (threadIdx.x == 0) s_nkeep = nk0;
+    __syncthreads();
+    for (int c = 0; c < nC; ++c) {
+        if (wave == 0) {
+            const int nk = s_nkeep;
+            const unsigned long long d = s_tiles[nms_tile_id(c, c) * 64 + lane];
+            unsigned long long rem = uniform64(s_removed[c]);
+            unsigned long long K = 0;
+            unsigned long long cand = ~rem;
+            int room = max_keep - nk;
+            while (cand != 0 && room > 0) {
+                const int i = __ffsll((long long)cand) - 1;
+                K |= 1ull << i;
+                --room;
+                const unsigned lo = __builtin_amdgcn_readlane((unsigned)d, i);
+                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(d >> 32), i);
+                rem |= ((unsigned long long)hi << 32) | lo;
+                const unsigned long long above = i >= 63 ? 0ull : (~0ull << (i + 1));
+                cand = uniform64(~rem & above);
+            }
+            if (lane == 0) {
+                s_K[c] = K;
+                s_nkeep = nk + __popcll(K);
+            }
+        }
+        __syncthreads();
+        const unsigned long long K = s_K[c];
+        const bool done = s_nkeep >= max_keep;
+        if (!done && K != 0) {
+            const int cb = c + 1 + wave; // at most 15 later blocks: one per wave
+            if (cb < nC) {
+                unsigned long long v = s_tiles[nms_tile_id(c, cb) * 64 + lane];
+                v = ((K >> lane) & 1ull) ? v : 0ull;
+                v = wave_or64(v);
+                if (lane == 0) s_removed[cb] |= v;
+            }
+        }
+        __syncthreads();
+        if (done) break;
+    }
+    // append the round's survivors to the kept list (positions from the per-block keep words)
+    {
+        const int c = wave, t = threadIdx.x;
+        const unsigned long long K = s_K[c];
+        if (c < nC && ((K >> lane) & 1ull)) {
+            int pos = nk0 + __popcll(K & ((1ull << lane) - 1ull));
+            for (int cc = 0; cc < c; ++cc) pos += __popcll(s_K[cc]);
+            const float4 bxv = boxes[(long long)b * max_n + base + t];
+            w.kbox[pos] = bxv;
+            w.karea[pos] = frcnn_area(bxv.x, bxv.y, bxv.z, bxv.w);
+            keep_out[(long long)b * max_keep + pos] = base + t;
+        }
+    }
+    if (threadIdx.x == 0) {
+        *w.nkeep = s_nkeep;
+        n_keep_out[b] = s_nkeep;
+    }
+}
+
+#define NMS_LAZY_MAX_N 2048
+
 extern "C" size_t frcnn_nms_workspace_bytes(int B, int max_n)
 {
-    if (B <= 0 || max_n <= 0) return 0;
-    size_t W = ((size_t)max_n + 63) / 64;
-    return (size_t)B * W * W * 64 * sizeof(unsigned long long);
+    if (B <= 0 || max_n <= NMS_LAZY_MAX_N) return 0;
+    return (size_t)B * nms_ws_stride(max_n);
 }
 
 // Largest fp32 t with (double)t <= thr:  (double)x > thr  <=>  x > t  for every fp32 x.
@@ -315,8 +412,9 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
     FRCNN_REQUIRE(B >= 0 && max_n >= 0 && max_keep >= 0, "nms: bad shape");
     if (B == 0) return FRCNN_OK;
     FRCNN_REQUIRE(n_keep_out, "nms: null n_keep_out");
+    hipStream_t st = (hipStream_t)stream;
     if (max_n == 0 || max_keep == 0) {
-        hipError_t e = hipMemsetAsync(n_keep_out, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
+        hipError_t e = hipMemsetAsync(n_keep_out, 0, sizeof(int32_t) * (size_t)B, st);
         FRCNN_REQUIRE(e == hipSuccess, "nms: memset failed: %s", hipGetErrorString(e));
         return FRCNN_OK;
     }
@@ -324,46 +422,50 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
     FRCNN_REQUIRE(iou_threshold == iou_threshold, "nms: NaN threshold");
     FRCNN_REQUIRE(B <= 65535, "nms: batch too large");
     const float thr = threshold_round_down(iou_threshold);
+    const int cap = max_keep < max_n ? max_keep : max_n; // no more than max_n boxes can be kept
 
-    // Lazy path: the kept list (20 B per keep) must fit in LDS.  keep_out has max_keep columns,
-    // but no more than max_n boxes can ever be kept.
-    const int cap = max_keep < max_n ? max_keep : max_n;
-    const size_t lazy_lds = (size_t)cap * 24;
-    if (lazy_lds <= NMS_LAZY_LDS_LIMIT) {
+    if (max_n <= NMS_LAZY_MAX_N) { // kept list (24 B per keep) fits LDS: one launch
+        const size_t lazy_lds = (size_t)cap * 24;
         static size_t configured = 48 * 1024;
         if (lazy_lds > configured) {
             hipError_t e = hipFuncSetAttribute((const void *)nms_lazy_kernel,
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               NMS_LAZY_LDS_LIMIT);
+                                               NMS_LAZY_MAX_N * 24);
             FRCNN_REQUIRE(e == hipSuccess, "nms: cannot reserve LDS: %s", hipGetErrorString(e));
-            configured = NMS_LAZY_LDS_LIMIT;
+            configured = NMS_LAZY_MAX_N * 24;
         }
-        hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds,
-                           (hipStream_t)stream, (const float4 *)boxes, n_per_image, max_n, thr,
-                           max_keep, cap, keep_out, n_keep_out);
+        hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
+                           (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out,
+                           n_keep_out);
         FRCNN_CHECK_LAUNCH("nms_lazy");
         return FRCNN_OK;
     }
 
-    // Bitmask path (very large keep budgets): full upper-triangular suppression matrix + scan.
     FRCNN_REQUIRE(workspace, "nms: null workspace");
-    if (workspace_bytes < frcnn_nms_workspace_bytes(B, max_n)) {
-        frcnn_set_error("nms: workspace too small (%zu < %zu)", workspace_bytes,
-                        frcnn_nms_workspace_bytes(B, max_n));
+    const size_t need = frcnn_nms_workspace_bytes(B, max_n);
+    if (workspace_bytes < need) {
+        frcnn_set_error("nms: workspace too small (%zu < %zu)", workspace_bytes, need);
         return FRCNN_EWORKSPACE;
     }
-    const int W = (max_n + 63) / 64;
-    FRCNN_REQUIRE((size_t)W * 8 <= 60 * 1024, "nms: max_n too large for the scan's LDS bitmap");
-    int col_groups = (W + 4 * NMS_COL_WAVES - 1) / (4 * NMS_COL_WAVES); // ~4 column blocks per wave
-    if (col_groups < 1) col_groups = 1;
-    if (col_groups > 64) col_groups = 64;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(W, col_groups, B), dim3(64 * NMS_COL_WAVES), 0,
-                       (hipStream_t)stream, (const float4 *)boxes, n_per_image, max_n, W, thr,
-                       (unsigned long long *)workspace);
-    FRCNN_CHECK_LAUNCH("nms_mask");
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(NMS_SCAN_THREADS), (size_t)W * 8,
-                       (hipStream_t)stream, (const unsigned long long *)workspace, n_per_image,
-                       max_n, W, max_keep, keep_out, n_keep_out);
-    FRCNN_CHECK_LAUNCH("nms_scan");
+    // the kept-list capacity of the workspace is max_n whatever max_keep is
+    const size_t stride = nms_ws_stride(max_n);
+    {   // zero every image's pull words and keep counter (the tail of each image's slab)
+        hipError_t e = hipMemsetAsync(workspace, 0, (size_t)B * stride, st);
+        FRCNN_REQUIRE(e == hipSuccess, "nms: memset failed: %s", hipGetErrorString(e));
+    }
+    const int rounds = (max_n + NMS_RS - 1) / NMS_RS;
+    int rsplit = (1024 + NMS_RC * B - 1) / (NMS_RC * B); // pull slices: ~1024 workgroups in flight
+    if (rsplit < 1) rsplit = 1;
+    if (rsplit > 16) rsplit = 16;
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(nms_round_pm_kernel, dim3(NMS_RC, rsplit + NMS_TILE_GROUPS, B), dim3(256), 0, st,
+                           (const float4 *)boxes, n_per_image, max_n, thr, max_keep, max_n, r, rsplit,
+                           (char *)workspace, stride);
+        FRCNN_CHECK_LAUNCH("nms_round_pm");
+        hipLaunchKernelGGL(nms_round_scan_kernel, dim3(B), dim3(1024), 0, st, (const float4 *)boxes,
+                           n_per_image, max_n, max_keep, max_n, r, (char *)workspace, stride, keep_out,
+                           n_keep_out);
+        FRCNN_CHECK_LAUNCH("nms_round_scan");
+    }
     return FRCNN_OK;
 }

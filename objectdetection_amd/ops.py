@@ -214,8 +214,7 @@ def nms_sorted(boxes, n_per_image, iou_threshold, max_keep):
     keep = torch.empty((B, max(max_keep, 1)), dtype=torch.int32, device=dev)
     n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
     lib = _lib.load()
-    # the suppression-matrix workspace is only needed when the kept list cannot live in LDS
-    nbytes = lib.frcnn_nms_workspace_bytes(B, n) if min(max_keep, n) * 24 > 120 * 1024 else 0
+    nbytes = lib.frcnn_nms_workspace_bytes(B, n)  # 0 for small n (single-launch path)
     ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
     if n_per_image is not None and n_per_image.dtype != torch.int32:
         n_per_image = n_per_image.to(torch.int32)
