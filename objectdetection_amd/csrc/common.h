@@ -57,6 +57,49 @@ __device__ __forceinline__ float frcnn_iou(float ax1, float ay1, float ax2, floa
     return inter / ((aarea + barea) - inter);
 }
 
+// Intersection and union terms of the IoU above, for callers that only need a threshold decision.
+__device__ __forceinline__ void frcnn_inter_union(float ax1, float ay1, float ax2, float ay2,
+                                                  float aarea, float bx1, float by1, float bx2,
+                                                  float by2, float barea, float *inter, float *uni)
+{
+    float ltx = ax1 > bx1 ? ax1 : bx1;
+    float lty = ay1 > by1 ? ay1 : by1;
+    float rbx = ax2 < bx2 ? ax2 : bx2;
+    float rby = ay2 < by2 ? ay2 : by2;
+    float jw = rbx - ltx;
+    float jh = rby - lty;
+    jw = jw < 0.0f ? 0.0f : jw;
+    jh = jh < 0.0f ? 0.0f : jh;
+    *inter = jw * jh;
+    *uni = (aarea + barea) - *inter;
+}
+
+// Threshold test of NMS, bit-identical to `RN(inter / uni) > t` (t = largest fp32 <= the double
+// threshold) but without a division in the common case.
+//   With t2 = the next fp32 above t, the test is RN(inter/uni) >= t2.  p = RN(t2 * uni) has a
+//   relative error <= 2^-24, so when inter differs from p by more than 2^-20 |p| the exact quotient
+//   is at least 4 ulps away from t2 on that side and its rounding cannot cross t2.  Only inside
+//   that band (about one pair in 2^20), or when uni is not a positive normal number (degenerate or
+//   NaN boxes) or the threshold itself is not a positive normal, is the IEEE division evaluated.
+struct FrcnnThr {
+    float t;    // largest fp32 <= threshold (double)
+    float t2;   // next fp32 above t
+    int fast;   // t2 is a positive normal number: the multiply test is valid
+};
+
+__device__ __forceinline__ bool frcnn_iou_gt(float inter, float uni, const FrcnnThr &th)
+{
+    const float p = th.t2 * uni;
+    const float d = inter - p;
+    const bool sure = th.fast && (p > 1e-30f) && (p < 3.0e38f) && (fabsf(d) > p * 9.5367431640625e-07f);
+    bool r = d > 0.0f;
+    if (__builtin_expect(__any(!sure), 0)) { // wave-uniform: taken about once per 2^14 wave tests
+        const bool slow = (inter / uni) > th.t;
+        r = sure ? r : slow;
+    }
+    return r;
+}
+
 // Order-preserving unsigned key of an fp32 score: larger key = ranks first.
 // NaN -> 0xFFFFFFFF (above +inf, as torch.topk treats NaN), -0.0 below +0.0.
 __device__ __forceinline__ uint32_t frcnn_score_key(float s)

@@ -62,7 +62,7 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane)
 
 __global__ void __launch_bounds__(NMS_LAZY_THREADS)
 nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image, int max_n,
-                float thr, int max_keep, int cap, int32_t *__restrict__ keep_out,
+                FrcnnThr thr, int max_keep, int cap, int32_t *__restrict__ keep_out,
                 int32_t *__restrict__ n_keep_out)
 {
     // dynamic LDS: [cap] kept boxes (float4), [cap] kept areas, [cap] kept positions
@@ -104,8 +104,9 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
             bool sup = false;
             for (int r = wave; r < nk; r += NMS_LAZY_WAVES) {
                 float4 k = s_kbox[r];
-                float iou = frcnn_iou(k.x, k.y, k.z, k.w, s_karea[r], cb.x, cb.y, cb.z, cb.w, carea);
-                sup = sup || (iou > thr);
+                float inter, uni;
+                frcnn_inter_union(k.x, k.y, k.z, k.w, s_karea[r], cb.x, cb.y, cb.z, cb.w, carea, &inter, &uni);
+                sup = sup | frcnn_iou_gt(inter, uni, thr);
             }
             unsigned long long m = __ballot(sup);
             if (lane == 0 && m != 0) {
@@ -129,8 +130,9 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
                         float rx1 = lane_bcast(cb.x, i), ry1 = lane_bcast(cb.y, i);
                         float rx2 = lane_bcast(cb.z, i), ry2 = lane_bcast(cb.w, i);
                         float rarea = lane_bcast(carea, i);
-                        float iou = frcnn_iou(rx1, ry1, rx2, ry2, rarea, cb.x, cb.y, cb.z, cb.w, carea);
-                        unsigned long long w = __ballot(lane > i && iou > thr);
+                        float inter, uni;
+                        frcnn_inter_union(rx1, ry1, rx2, ry2, rarea, cb.x, cb.y, cb.z, cb.w, carea, &inter, &uni);
+                        unsigned long long w = __ballot(frcnn_iou_gt(inter, uni, thr) && lane > i);
                         if (lane == 0) s_row[i] = w;
                     }
                     ++a;
@@ -238,7 +240,7 @@ __device__ __forceinline__ int nms_tile_id(int rb, int cb)
 // Kernel PM of a round.  grid = (16 candidate blocks, RSPLIT pull slices + tile slices, B).
 __global__ void __launch_bounds__(256)
 nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
-                    int max_n, float thr, int max_keep, int cap, int round, int rsplit, char *ws,
+                    int max_n, FrcnnThr thr, int max_keep, int cap, int round, int rsplit, char *ws,
                     size_t ws_stride)
 {
     const int b = blockIdx.z;
@@ -263,8 +265,9 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
         const int step = rsplit * 4;
         for (int r = blockIdx.y * 4 + wave; r < nk; r += step) {
             const float4 k = w.kbox[r];
-            const float iou = frcnn_iou(k.x, k.y, k.z, k.w, w.karea[r], cb.x, cb.y, cb.z, cb.w, carea);
-            sup = sup || (iou > thr);
+            float inter, uni;
+            frcnn_inter_union(k.x, k.y, k.z, k.w, w.karea[r], cb.x, cb.y, cb.z, cb.w, carea, &inter, &uni);
+            sup = sup | frcnn_iou_gt(inter, uni, thr);
         }
         const unsigned long long m = __ballot(sup);
         if (lane == 0 && m != 0) atomicOr(&w.sup[c], m);
@@ -281,7 +284,10 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
         const float rarea = frcnn_area(rbx.x, rbx.y, rbx.z, rbx.w);
         const float carea = frcnn_area(cbx.x, cbx.y, cbx.z, cbx.w);
         const bool diag = rb == cbk;
-        unsigned long long word = 0;
+        // COLUMN words: bit i of lane c's word = "row candidate i suppresses column candidate c".
+        // With the suppressors of a candidate in its own lane, the scan kernel needs no cross-lane
+        // reduction: `(word & kept_mask) != 0` is lane-local and a ballot collects the block.
+        unsigned lo = 0, hi = 0;
 #pragma unroll 8
         for (int i = 0; i < 64; ++i) {
             const float x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.x), i));
@@ -289,10 +295,15 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
             const float x2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.z), i));
             const float y2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.w), i));
             const float ra = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rarea), i));
-            const float iou = frcnn_iou(x1, y1, x2, y2, ra, cbx.x, cbx.y, cbx.z, cbx.w, carea);
-            const unsigned long long m = __ballot(ci < n && iou > thr && (!diag || lane > i));
-            if (lane == i) word = m;
+            float inter, uni;
+            frcnn_inter_union(x1, y1, x2, y2, ra, cbx.x, cbx.y, cbx.z, cbx.w, carea, &inter, &uni);
+            const bool sup = frcnn_iou_gt(inter, uni, thr) && ci < n && (!diag || lane > i);
+            if (i < 32)
+                lo |= sup ? (1u << i) : 0u;
+            else
+                hi |= sup ? (1u << (i - 32)) : 0u;
         }
+        const unsigned long long word = ((unsigned long long)hi << 32) | lo;
         w.tiles[(long long)id * 64 + lane] = word;
     }
 }
@@ -331,44 +342,55 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     }
     if (threadIdx.x == 0) s_nkeep = nk0;
     __syncthreads();
-    for (int c = 0; c < nC; ++c) {
-        if (wave == 0) {
-            const int nk = s_nkeep;
-            const unsigned long long d = s_tiles[nms_tile_id(c, c) * 64 + lane];
-            unsigned long long rem = uniform64(s_removed[c]);
-            unsigned long long K = 0;
-            unsigned long long cand = ~rem;
-            int room = max_keep - nk;
-            while (cand != 0 && room > 0) {
-                const int i = __ffsll((long long)cand) - 1;
-                K |= 1ull << i;
-                --room;
-                const unsigned lo = __builtin_amdgcn_readlane((unsigned)d, i);
-                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(d >> 32), i);
-                rem |= ((unsigned long long)hi << 32) | lo;
-                const unsigned long long above = i >= 63 ? 0ull : (~0ull << (i + 1));
-                cand = uniform64(~rem & above);
-            }
-            if (lane == 0) {
-                s_K[c] = K;
-                s_nkeep = nk + __popcll(K);
+    // One wave walks the 16 blocks with no barrier.  Lane j of block c holds col = the earlier
+    // candidates of the block that would suppress j.  Resolve = fixed-point iteration on uniform
+    // masks: a candidate is removed once a KEPT one suppresses it, and kept once no kept or still
+    // undecided one does; the lowest undecided candidate is always decidable, so the loop ends
+    // after (dependency-chain depth) <= 64 passes of ~10 instructions, typically 1-3.  Folding the
+    // block's keeps into a later block is `ballot((col & K) != 0)` on that block's tile.
+    if (wave == 0) {
+        unsigned long long removed[NMS_RC];
+#pragma unroll
+        for (int cb = 0; cb < NMS_RC; ++cb) removed[cb] = uniform64(s_removed[cb]);
+        int nk = nk0;
+#pragma unroll
+        for (int c = 0; c < NMS_RC; ++c) {
+            if (c < nC && nk < max_keep) {
+                const int tb = nms_tile_id(c, c);
+                const unsigned long long col = s_tiles[tb * 64 + lane];
+                unsigned long long U = ~removed[c]; // undecided
+                unsigned long long K = 0;           // decided: kept
+                while (U != 0) {
+                    const bool inU = (U >> lane) & 1ull;
+                    const bool killed = (col & K) != 0;
+                    const bool blocked = (col & U) != 0;
+                    const unsigned long long rem_now = __ballot(inU && killed);
+                    const unsigned long long keep_now = __ballot(inU && !killed && !blocked);
+                    K |= keep_now;
+                    U &= ~(rem_now | keep_now);
+                }
+                // only the first (max_keep - nk) keeps count: drop the highest surplus bits
+                int surplus = __popcll(K) - (max_keep - nk);
+                while (surplus > 0) {
+                    K &= ~(1ull << (63 - __clzll((long long)K)));
+                    --surplus;
+                }
+                if (lane == 0) s_K[c] = K;
+                nk += __popcll(K);
+                if (K != 0 && nk < max_keep) {
+#pragma unroll
+                    for (int cb = c + 1; cb < NMS_RC; ++cb) {
+                        if (cb < nC) {
+                            const unsigned long long cw = s_tiles[(tb + cb - c) * 64 + lane];
+                            removed[cb] |= __ballot((cw & K) != 0);
+                        }
+                    }
+                }
             }
         }
-        __syncthreads();
-        const unsigned long long K = s_K[c];
-        const bool done = s_nkeep >= max_keep;
-        if (!done && K != 0) {
-            const int cb = c + 1 + wave; // at most 15 later blocks: one per wave
-            if (cb < nC) {
-                unsigned long long v = s_tiles[nms_tile_id(c, cb) * 64 + lane];
-                v = ((K >> lane) & 1ull) ? v : 0ull;
-                v = wave_or64(v);
-                if (lane == 0) s_removed[cb] |= v;
-            }
-        }
-        __syncthreads();
-        if (done) break;
+        if (lane == 0) s_nkeep = nk;
     }
+    __syncthreads();
     // append the round's survivors to the kept list (positions from the per-block keep words)
     {
         const int c = wave, t = threadIdx.x;
@@ -396,12 +418,15 @@ extern "C" size_t frcnn_nms_workspace_bytes(int B, int max_n)
     return (size_t)B * nms_ws_stride(max_n);
 }
 
-// Largest fp32 t with (double)t <= thr:  (double)x > thr  <=>  x > t  for every fp32 x.
-static float threshold_round_down(double thr)
+// t = largest fp32 with (double)t <= thr:  (double)x > thr  <=>  x > t  for every fp32 x.
+static FrcnnThr make_threshold(double thr)
 {
-    float t = (float)thr;
-    if ((double)t > thr) t = nextafterf(t, -INFINITY);
-    return t;
+    FrcnnThr th;
+    th.t = (float)thr;
+    if ((double)th.t > thr) th.t = nextafterf(th.t, -INFINITY);
+    th.t2 = nextafterf(th.t, INFINITY);
+    th.fast = (th.t2 >= 1e-6f && th.t2 < 1e6f) ? 1 : 0;
+    return th;
 }
 
 extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
@@ -421,7 +446,7 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
     FRCNN_REQUIRE(boxes && keep_out, "nms: null pointer");
     FRCNN_REQUIRE(iou_threshold == iou_threshold, "nms: NaN threshold");
     FRCNN_REQUIRE(B <= 65535, "nms: batch too large");
-    const float thr = threshold_round_down(iou_threshold);
+    const FrcnnThr thr = make_threshold(iou_threshold);
     const int cap = max_keep < max_n ? max_keep : max_n; // no more than max_n boxes can be kept
 
     if (max_n <= NMS_LAZY_MAX_N) { // kept list (24 B per keep) fits LDS: one launch
