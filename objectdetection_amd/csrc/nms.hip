@@ -187,6 +187,7 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
 #define NMS_RS 1024                       // candidates per round
 #define NMS_RC (NMS_RS / 64)              // 64-candidate blocks per round (16)
 #define NMS_RT (NMS_RC * (NMS_RC + 1) / 2) // upper-triangular tiles per round (136)
+#define NMS_DENSE 512                     // survivors per round from which chip-wide tiles pay off
 #define NMS_TILE_GROUPS ((NMS_RT + NMS_RC * 4 - 1) / (NMS_RC * 4)) // grid.y slices of tile waves (3)
 
 // Per-image workspace of the round path (all offsets 16-byte aligned).
@@ -196,6 +197,7 @@ struct NmsWs {
     unsigned long long *tiles; // [NMS_RT][64] this round's suppression tiles, tile-major
     unsigned long long *sup;   // [NMS_RC] this round's pull result (zero between rounds)
     int *nkeep;                // [1]
+    int *dense;                // [1] last round left >= NMS_DENSE survivors of the pull: precompute tiles
 };
 
 static size_t nms_ws_stride(int cap)
@@ -217,6 +219,7 @@ __device__ __forceinline__ NmsWs nms_ws(char *base, size_t stride, int b, int ca
     w.sup = (unsigned long long *)p;
     p += 256;
     w.nkeep = (int *)p;
+    w.dense = w.nkeep + 1;
     return w;
 }
 
@@ -275,6 +278,9 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
         // ---- tiles: wave = one 64x64 tile of the round's own candidates
         const int id = (((int)blockIdx.y - rsplit) * NMS_RC + blockIdx.x) * 4 + wave;
         if (id >= NMS_RT) return;
+        // chip-wide tiles only pay off when most of the round survives the pull; the scan kernel
+        // builds the few tiles of a sparse round itself (it records which case the last round was)
+        if (round != 0 && *w.dense == 0) return;
         int rb, cbk;
         nms_tile_rc(id, &rb, &cbk);
         if (base + cbk * 64 >= n) return;
@@ -308,13 +314,45 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
     }
 }
 
-// Kernel L of a round: one workgroup per image resolves the round's 16 candidate blocks in order.
+// One 64x64 tile of COLUMN words over a candidate list held in LDS: lane = column candidate
+// cb*64+lane, rows rb*64+i broadcast from LDS.  Bit i of a lane's word = "row i suppresses me".
+__device__ __forceinline__ unsigned long long nms_tile_from_lds(const float4 *s_box, int count, int rb,
+                                                                int cb, int lane, const FrcnnThr &thr)
+{
+    const int ci = cb * 64 + lane;
+    const float4 c = s_box[ci];
+    const float carea = frcnn_area(c.x, c.y, c.z, c.w);
+    const bool diag = rb == cb;
+    unsigned lo = 0, hi = 0;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+        const float4 r = s_box[rb * 64 + i];
+        float inter, uni;
+        frcnn_inter_union(r.x, r.y, r.z, r.w, frcnn_area(r.x, r.y, r.z, r.w), c.x, c.y, c.z, c.w, carea,
+                          &inter, &uni);
+        const bool sup = frcnn_iou_gt(inter, uni, thr) && ci < count && rb * 64 + i < count &&
+                         (!diag || lane > i);
+        if (i < 32)
+            lo |= sup ? (1u << i) : 0u;
+        else
+            hi |= sup ? (1u << (i - 32)) : 0u;
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Kernel L of a round: one workgroup per image resolves the round's candidates in order.
+// It works on a LIST of candidates in LDS: the identity list with the pull's suppression words when
+// most of the round survived the pull (dense: tiles come from kernel PM), or the compacted list of
+// survivors when few did (sparse: the handful of tiles is built here by the 16 waves).
 __global__ void __launch_bounds__(1024)
 nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
-                      int max_n, int max_keep, int cap, int round, char *ws, size_t ws_stride,
-                      int32_t *__restrict__ keep_out, int32_t *__restrict__ n_keep_out)
+                      int max_n, FrcnnThr thr, int max_keep, int cap, int round, char *ws,
+                      size_t ws_stride, int32_t *__restrict__ keep_out,
+                      int32_t *__restrict__ n_keep_out)
 {
     __shared__ unsigned long long s_tiles[NMS_RT * 64];
+    __shared__ float4 s_box[NMS_RS];   // the list's boxes
+    __shared__ int s_pos[NMS_RS];      // the list's positions inside the round
     __shared__ unsigned long long s_removed[NMS_RC];
     __shared__ unsigned long long s_K[NMS_RC];
     __shared__ int s_nkeep;
@@ -327,27 +365,68 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
         if (threadIdx.x == 0) n_keep_out[b] = nk0;
         return;
     }
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
     const int cnt = min(NMS_RS, n - base);
-    const int nC = (cnt + 63) >> 6;
-    for (int t = threadIdx.x; t < NMS_RT * 64; t += 1024) s_tiles[t] = w.tiles[t];
-    if (threadIdx.x < NMS_RC) {
-        const int c = threadIdx.x;
-        const int rows = min(64, cnt - c * 64);
+    const bool pm_tiles = round == 0 || *w.dense != 0; // what kernel PM decided for this image
+    // survivors of the pull
+    unsigned long long pulled = 0;
+    if (t < NMS_RC) {
+        const int rows = min(64, cnt - t * 64);
         const unsigned long long valid = rows >= 64 ? ~0ull : (rows <= 0 ? 0ull : ((1ull << rows) - 1ull));
-        s_removed[c] = w.sup[c] | ~valid;
-        s_K[c] = 0;
-        w.sup[c] = 0; // ready for the next round's atomicOr
+        pulled = w.sup[t] | ~valid;
+        s_removed[t] = pulled;
+        s_K[t] = 0;
+        w.sup[t] = 0; // ready for the next round's atomicOr
     }
-    if (threadIdx.x == 0) s_nkeep = nk0;
+    if (t == 0) s_nkeep = nk0;
     __syncthreads();
-    // One wave walks the 16 blocks with no barrier.  Lane j of block c holds col = the earlier
-    // candidates of the block that would suppress j.  Resolve = fixed-point iteration on uniform
-    // masks: a candidate is removed once a KEPT one suppresses it, and kept once no kept or still
-    // undecided one does; the lowest undecided candidate is always decidable, so the loop ends
-    // after (dependency-chain depth) <= 64 passes of ~10 instructions, typically 1-3.  Folding the
-    // block's keeps into a later block is `ballot((col & K) != 0)` on that block's tile.
+    int alive = 0;
+    for (int c = 0; c < NMS_RC; ++c) alive += 64 - __popcll(s_removed[c]);
+    const bool dense = alive >= NMS_DENSE;
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 mybox = t < cnt ? boxes[(long long)b * max_n + base + t] : zero4;
+    int count; // length of the list
+    if (dense) {
+        count = cnt;
+        s_box[t] = mybox;
+        s_pos[t] = t;
+        __syncthreads();
+    } else {
+        count = alive;
+        const unsigned long long rm = s_removed[wave];
+        int rank = 0;
+        for (int c = 0; c < wave; ++c) rank += 64 - __popcll(s_removed[c]);
+        rank += lane - __popcll(rm & ((1ull << lane) - 1ull));
+        __syncthreads(); // everyone has read the pull words
+        if (!((rm >> lane) & 1ull)) {
+            s_box[rank] = mybox;
+            s_pos[rank] = t;
+        }
+        if (t < NMS_RC) { // the compacted list starts with nothing removed but its tail
+            const int rows = min(64, count - t * 64);
+            s_removed[t] = rows >= 64 ? 0ull : (rows <= 0 ? ~0ull : ~((1ull << rows) - 1ull));
+        }
+        __syncthreads();
+    }
+    const int nC = (count + 63) >> 6;
+    if (dense && pm_tiles) {
+        for (int i = t; i < NMS_RT * 64; i += 1024) s_tiles[i] = w.tiles[i];
+    } else {
+        for (int id = wave; id < NMS_RT; id += 16) {
+            int rb, cb;
+            nms_tile_rc(id, &rb, &cb);
+            if (cb < nC) s_tiles[id * 64 + lane] = nms_tile_from_lds(s_box, count, rb, cb, lane, thr);
+        }
+    }
+    __syncthreads();
+    // One wave walks the blocks of the list with no barrier.  Lane j of block c holds col = the
+    // earlier candidates of the block that would suppress j.  Resolve = fixed-point iteration on
+    // uniform masks: a candidate is removed once a KEPT one suppresses it, and kept once no kept or
+    // still undecided one does; the lowest undecided candidate is always decidable, so the loop
+    // ends after (dependency-chain depth) <= 64 passes of ~10 instructions, typically 1-3.  Folding
+    // the block's keeps into a later block is `ballot((col & K) != 0)` on that block's tile.
     if (wave == 0) {
         unsigned long long removed[NMS_RC];
 #pragma unroll
@@ -391,21 +470,21 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
         if (lane == 0) s_nkeep = nk;
     }
     __syncthreads();
-    // append the round's survivors to the kept list (positions from the per-block keep words)
+    // append the round's keeps to the kept list (list order = candidate order)
     {
-        const int c = wave, t = threadIdx.x;
-        const unsigned long long K = s_K[c];
-        if (c < nC && ((K >> lane) & 1ull)) {
+        const unsigned long long K = s_K[wave];
+        if (wave < nC && ((K >> lane) & 1ull)) {
             int pos = nk0 + __popcll(K & ((1ull << lane) - 1ull));
-            for (int cc = 0; cc < c; ++cc) pos += __popcll(s_K[cc]);
-            const float4 bxv = boxes[(long long)b * max_n + base + t];
+            for (int cc = 0; cc < wave; ++cc) pos += __popcll(s_K[cc]);
+            const float4 bxv = s_box[t];
             w.kbox[pos] = bxv;
             w.karea[pos] = frcnn_area(bxv.x, bxv.y, bxv.z, bxv.w);
-            keep_out[(long long)b * max_keep + pos] = base + t;
+            keep_out[(long long)b * max_keep + pos] = base + s_pos[t];
         }
     }
-    if (threadIdx.x == 0) {
+    if (t == 0) {
         *w.nkeep = s_nkeep;
+        *w.dense = dense ? 1 : 0;
         n_keep_out[b] = s_nkeep;
     }
 }
@@ -488,8 +567,8 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
                            (char *)workspace, stride);
         FRCNN_CHECK_LAUNCH("nms_round_pm");
         hipLaunchKernelGGL(nms_round_scan_kernel, dim3(B), dim3(1024), 0, st, (const float4 *)boxes,
-                           n_per_image, max_n, max_keep, max_n, r, (char *)workspace, stride, keep_out,
-                           n_keep_out);
+                           n_per_image, max_n, thr, max_keep, max_n, r, (char *)workspace, stride,
+                           keep_out, n_keep_out);
         FRCNN_CHECK_LAUNCH("nms_round_scan");
     }
     return FRCNN_OK;
