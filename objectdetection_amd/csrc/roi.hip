@@ -265,6 +265,7 @@ __device__ __forceinline__ AxisSample axis_sample(float v, int n)
 }
 
 #define RAP_THREADS 1024
+#define RAP_SEG 512 // RoIs whose geometry is staged in LDS at a time (10 KB)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -303,6 +304,8 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
                        float *__restrict__ out, int32_t *__restrict__ total_out)
 {
     extern __shared__ float4 s_plane[];
+    __shared__ float4 s_rec[RAP_SEG]; // per RoI: start_w, start_h, bin_w, bin_h (feature pixels)
+    __shared__ int s_lvl[RAP_SEG];    // per RoI: pyramid level that pools it, -1 = none
     __shared__ int s_off, s_cnt;
     const int b = blockIdx.z;
     const int B = gridDim.z;
@@ -343,83 +346,105 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
     const int per = (cnt + gridDim.y - 1) / gridDim.y;
     const int j0 = blockIdx.y * per;
     const int j1 = min(cnt, j0 + per);
-    if (j0 >= j1) return;
-    // item = (RoI, bin): its 16 tap addresses and weights are computed once and reused for every
-    // channel group of the chunk
-    const int items = (j1 - j0) * 49;
     const int row_stride = G * WS;
     const float4 *pb = props + (long long)b * P;
     float *ob = out + ((long long)s_off * C + c0) * 49;
-    for (int t = threadIdx.x; t < items; t += RAP_THREADS) {
-        int jl = t / 49;
-        int bin = t - jl * 49;
-        int ph = bin / 7, pw = bin - ph * 7;
-        int j = j0 + jl;
-        float4 box = pb[j];
-        float *o = ob + (long long)j * C * 49 + bin;
-        bool pool = true;
-        if (n_levels > 1) {
-            int lv = map_level(box, k_min, k_max);
-            bool none = lv < 0 || lv >= n_levels; // no level takes it: level 0's pass writes zeros
-            if (none && level == 0) {
-                for (int c = 0; c < nc; ++c) o[c * 49] = 0.0f;
+    // RoIs are taken RAP_SEG at a time: their geometry goes to LDS first, so that the item loop
+    // below issues NO global loads.  The memory counter retires loads and stores in order; a box
+    // load inside the loop made every iteration wait for the previous iteration's 16 stores to
+    // reach L2 (a full store round trip per item -- that stall, not LDS or ALU work, bounded the
+    // kernel).  With the loop load-free the stores are fire-and-forget.
+    for (int seg = j0; seg < j1; seg += RAP_SEG) {
+        const int nseg = min(RAP_SEG, j1 - seg);
+        __syncthreads(); // readers of the previous segment's records are done
+        for (int i = threadIdx.x; i < nseg; i += RAP_THREADS) {
+            float4 box = pb[seg + i];
+            int lv = 0;
+            if (n_levels > 1) {
+                lv = map_level(box, k_min, k_max);
+                lv = (lv < 0 || lv >= n_levels) ? -1 : lv;
             }
-            pool = lv == level;
+            float start_w = box.x * scale, start_h = box.y * scale;
+            float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
+            roi_w = roi_w > 1.0f ? roi_w : 1.0f;
+            roi_h = roi_h > 1.0f ? roi_h : 1.0f;
+            s_rec[i] = make_float4(start_w, start_h, roi_w / 7.0f, roi_h / 7.0f);
+            s_lvl[i] = lv;
         }
-        if (!pool) continue;
-        float start_w = box.x * scale, start_h = box.y * scale;
-        float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
-        roi_w = roi_w > 1.0f ? roi_w : 1.0f;
-        roi_h = roi_h > 1.0f ? roi_h : 1.0f;
-        float bin_h = roi_h / 7.0f, bin_w = roi_w / 7.0f;
-        AxisSample ys[2], xs[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
-            xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
-        }
-        // 4 row terms + 4 column terms, then one (xor, add) and one multiply per tap; the 1/4 of
-        // the 2x2 average is folded into the row weights (exact: power of two)
-        const int yr[4] = {ys[0].lo, ys[0].hi, ys[1].lo, ys[1].hi};
-        const int xc[4] = {xs[0].lo, xs[0].hi, xs[1].lo, xs[1].hi};
-        const float rw[4] = {ys[0].wlo * 0.25f, ys[0].whi * 0.25f, ys[1].wlo * 0.25f, ys[1].whi * 0.25f};
-        const float cw[4] = {xs[0].wlo, xs[0].whi, xs[1].wlo, xs[1].whi};
-        int off[16];
-        float wt[16];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rb = __mul24(yr[r], row_stride);
-            const int sw = rap_swz(yr[r]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                off[r * 4 + c] = (xc[c] ^ sw) + rb;
-                wt[r * 4 + c] = rw[r] * cw[c];
+        __syncthreads();
+        // item = (RoI, bin): its 16 tap addresses and weights are computed once and reused for
+        // every channel group of the chunk.  Each WAVE walks a contiguous run of whole RoIs, 64 items
+        // per iteration: a wave then writes every 3136-byte (RoI, chunk) piece of the output by
+        // itself, back to back.  With items strided over the block instead, the two parts of each
+        // 196-byte channel run came from different waves and the store stream ran 1.4x slower
+        // (tools/store_probe.hip, modes 16 and 23).
+        const int rpw = (nseg + RAP_THREADS / 64 - 1) / (RAP_THREADS / 64);
+        const int ja = min(nseg, (int)(threadIdx.x >> 6) * rpw);
+        const int items = (min(nseg, ja + rpw) - ja) * 49;
+        for (int t = threadIdx.x & 63; t < items; t += 64) {
+            int jl = t / 49;
+            int bin = t - jl * 49;
+            int ph = bin / 7, pw = bin - ph * 7;
+            jl += ja;
+            const float4 rec = s_rec[jl];
+            float *o = ob + (long long)(seg + jl) * C * 49 + bin;
+            if (n_levels > 1) {
+                const int lv = s_lvl[jl];
+                if (lv < 0 && level == 0) { // no level takes it: level 0's pass writes zeros
+                    for (int c = 0; c < nc; ++c) o[c * 49] = 0.0f;
+                }
+                if (lv != level) continue;
             }
-        }
-        if (GT) {
+            const float start_w = rec.x, start_h = rec.y, bin_w = rec.z, bin_h = rec.w;
+            AxisSample ys[2], xs[2];
 #pragma unroll
-            for (int g = 0; g < (GT ? GT : 1); ++g) {
-                const float4 *pl = s_plane + g * WS; // immediate offset when WST != 0
-                f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
-                float *og = o + (4 * g) * 49; // immediate store offsets
-                og[0] = lo.x;
-                og[49] = lo.y;
-                og[98] = hi.x;
-                og[147] = hi.y;
+            for (int i = 0; i < 2; ++i) {
+                ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
+                xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
             }
-        } else {
-            for (int g = 0; g < G; ++g) {
-                const float4 *pl = s_plane + g * WS;
-                f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+            // 4 row terms + 4 column terms, then one (xor, add) and one multiply per tap; the 1/4 of
+            // the 2x2 average is folded into the row weights (exact: power of two)
+            const int yr[4] = {ys[0].lo, ys[0].hi, ys[1].lo, ys[1].hi};
+            const int xc[4] = {xs[0].lo, xs[0].hi, xs[1].lo, xs[1].hi};
+            const float rw[4] = {ys[0].wlo * 0.25f, ys[0].whi * 0.25f, ys[1].wlo * 0.25f, ys[1].whi * 0.25f};
+            const float cw[4] = {xs[0].wlo, xs[0].whi, xs[1].wlo, xs[1].whi};
+            int off[16];
+            float wt[16];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
-                float *og = o + (4 * g) * 49;
-                og[0] = lo.x;
-                if (4 * g + 1 < nc) og[49] = lo.y;
-                if (4 * g + 2 < nc) og[98] = hi.x;
-                if (4 * g + 3 < nc) og[147] = hi.y;
+            for (int r = 0; r < 4; ++r) {
+                const int rb = __mul24(yr[r], row_stride);
+                const int sw = rap_swz(yr[r]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    off[r * 4 + c] = (xc[c] ^ sw) + rb;
+                    wt[r * 4 + c] = rw[r] * cw[c];
+                }
+            }
+            if (GT) {
+#pragma unroll
+                for (int g = 0; g < (GT ? GT : 1); ++g) {
+                    const float4 *pl = s_plane + g * WS; // immediate offset when WST != 0
+                    f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
+                    float *og = o + (4 * g) * 49; // immediate store offsets
+                    og[0] = lo.x;
+                    og[49] = lo.y;
+                    og[98] = hi.x;
+                    og[147] = hi.y;
+                }
+            } else {
+                for (int g = 0; g < G; ++g) {
+                    const float4 *pl = s_plane + g * WS;
+                    f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
+                    float *og = o + (4 * g) * 49;
+                    og[0] = lo.x;
+                    if (4 * g + 1 < nc) og[49] = lo.y;
+                    if (4 * g + 2 < nc) og[98] = hi.x;
+                    if (4 * g + 3 < nc) og[147] = hi.y;
+                }
             }
         }
     }
@@ -499,7 +524,7 @@ roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, in
     }
 }
 
-#define RAP_LDS_BUDGET (150 * 1024)
+#define RAP_LDS_BUDGET (148 * 1024) // dynamic part; 10.3 KB of static LDS (RoI records) on top
 
 extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W,
                                            const float *props, const int32_t *count, int P,

@@ -2,6 +2,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import objectdetection_amd._lib as _l
+if os.environ.get("FRCNN_EXP_LIB"):  # A/B builds of the library (experiments only)
+    _l.LIB_PATH = os.path.abspath(os.environ["FRCNN_EXP_LIB"])
 import bench
 
 what = sys.argv[1]; reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -17,6 +20,13 @@ props = ops.gather_boxes(boxes, keep, n_keep)
 fn = {"roi": lambda: path.pool.forward_padded({'1': feat}, props, n_keep, [(bench.IMG_H, bench.IMG_W)]),
       "nms": lambda: ops.nms_sorted(boxes, count, bench.NMS_THR, bench.POST_NMS),
       "topk": lambda: ops.topk_desc(scores, bench.PRE_NMS)}[what]
+if what == "roi" and os.environ.get("ROI_STATS"):
+    m = torch.arange(props.shape[1], device=dev)[None, :] < n_keep[:, None]
+    w = ((props[..., 2] - props[..., 0]) / 16.0)[m]; h = ((props[..., 3] - props[..., 1]) / 16.0)[m]
+    q = torch.tensor([0.1, 0.5, 0.9], device=dev)
+    print("roi w px q10/50/90", torch.quantile(w, q).tolist(), "mean", float(w.mean()),
+          "h", torch.quantile(h, q).tolist(), "mean", float(h.mean()),
+          "frac both<14", float(((w < 14) & (h < 14)).float().mean()), "frac w<14", float((w < 14).float().mean()))
 for _ in range(3): fn()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
