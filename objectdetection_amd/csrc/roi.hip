@@ -241,6 +241,7 @@ __device__ __forceinline__ int map_level(float4 p, int k_min, int k_max)
 struct AxisSample { // one 1-D bilinear sample: taps lo/hi with weights (zero when out of range)
     int lo, hi;
     float wlo, whi;
+    bool ok;
 };
 
 __device__ __forceinline__ AxisSample axis_sample(float v, int n)
@@ -261,6 +262,7 @@ __device__ __forceinline__ AxisSample axis_sample(float v, int n)
     a.hi = ok ? hi : 0;
     a.wlo = ok ? h : 0.0f;
     a.whi = ok ? l : 0.0f;
+    a.ok = ok;
     return a;
 }
 
@@ -288,6 +290,91 @@ __device__ __forceinline__ void pk_axpy4(f32x2 &lo, f32x2 &hi, float w, const fl
 __device__ __forceinline__ int rap_swz(int y)
 {
     return ((y & 1) << 3) | ((y & 2) << 1) | ((y & 4) >> 1) | ((y & 8) >> 3);
+}
+
+// The two samples of a bin along one axis touch 4 cells (lo0, hi0, lo1, hi1).  When the bin is at
+// most 2 pixels wide the samples are at most one cell apart, so the 4 taps fall on 3 consecutive
+// cells a, a+1, a+2 and their weights can be added up per cell: 3 LDS reads and 3 FMAs per row
+// instead of 4 (9 instead of 16 per bin when both axes merge).  Same sum, different rounding order
+// (a few ulp; parity with the oracle is to 1e-5, tests/test_gpu_parity.py).
+struct AxisTaps {
+    int idx[4];
+    float w[4];
+};
+
+__device__ __forceinline__ bool axis_mergeable(const AxisSample &s0, const AxisSample &s1)
+{
+    return s0.ok && s1.ok && (unsigned)(s1.lo - s0.lo) <= 1u;
+}
+
+__device__ __forceinline__ AxisTaps axis_taps4(const AxisSample &s0, const AxisSample &s1, float k)
+{
+    AxisTaps t;
+    t.idx[0] = s0.lo; t.idx[1] = s0.hi; t.idx[2] = s1.lo; t.idx[3] = s1.hi;
+    t.w[0] = s0.wlo * k; t.w[1] = s0.whi * k; t.w[2] = s1.wlo * k; t.w[3] = s1.whi * k;
+    return t;
+}
+
+__device__ __forceinline__ AxisTaps axis_taps3(const AxisSample &s0, const AxisSample &s1, float k, int n)
+{
+    AxisTaps t;
+    const bool same = s1.lo == s0.lo;
+    const int a = s0.lo;
+    t.idx[0] = a;
+    t.idx[1] = min(a + 1, n - 1);
+    t.idx[2] = min(a + 2, n - 1);
+    t.idx[3] = 0;
+    // a clamped sample (lo == n-1) has whi == 0, so treating its hi tap as cell lo+1 is exact
+    t.w[0] = (s0.wlo + (same ? s1.wlo : 0.0f)) * k;
+    t.w[1] = (s0.whi + (same ? s1.whi : s1.wlo)) * k;
+    t.w[2] = (same ? 0.0f : s1.whi) * k;
+    t.w[3] = 0.0f;
+    return t;
+}
+
+// All channel groups of one item: NY x NX taps, each ONE ds_read_b128 serving 4 channels.
+template <int NY, int NX, int GT>
+__device__ __forceinline__ void rap_item(const float4 *s_plane, int WS, int row_stride, int G, int nc,
+                                         const AxisTaps &ty, const AxisTaps &tx, float *o)
+{
+    int off[NY * NX];
+    float wt[NY * NX];
+#pragma unroll
+    for (int r = 0; r < NY; ++r) {
+        const int rb = __mul24(ty.idx[r], row_stride);
+        const int sw = rap_swz(ty.idx[r]);
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+            off[r * NX + c] = (tx.idx[c] ^ sw) + rb;
+            wt[r * NX + c] = ty.w[r] * tx.w[c];
+        }
+    }
+    if (GT) {
+#pragma unroll
+        for (int g = 0; g < (GT ? GT : 1); ++g) {
+            const float4 *pl = s_plane + g * WS; // immediate offset when WS is a compile-time constant
+            f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < NY * NX; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
+            float *og = o + (4 * g) * 49; // immediate store offsets
+            og[0] = lo.x;
+            og[49] = lo.y;
+            og[98] = hi.x;
+            og[147] = hi.y;
+        }
+    } else {
+        for (int g = 0; g < G; ++g) {
+            const float4 *pl = s_plane + g * WS;
+            f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < NY * NX; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
+            float *og = o + (4 * g) * 49;
+            og[0] = lo.x;
+            if (4 * g + 1 < nc) og[49] = lo.y;
+            if (4 * g + 2 < nc) og[98] = hi.x;
+            if (4 * g + 3 < nc) og[147] = hi.y;
+        }
+    }
 }
 
 // The profile that shaped this kernel (rocprofv3 PMC, MI355X): it is bound by vector-instruction
@@ -402,49 +489,22 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
                 ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
                 xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
             }
-            // 4 row terms + 4 column terms, then one (xor, add) and one multiply per tap; the 1/4 of
-            // the 2x2 average is folded into the row weights (exact: power of two)
-            const int yr[4] = {ys[0].lo, ys[0].hi, ys[1].lo, ys[1].hi};
-            const int xc[4] = {xs[0].lo, xs[0].hi, xs[1].lo, xs[1].hi};
-            const float rw[4] = {ys[0].wlo * 0.25f, ys[0].whi * 0.25f, ys[1].wlo * 0.25f, ys[1].whi * 0.25f};
-            const float cw[4] = {xs[0].wlo, xs[0].whi, xs[1].wlo, xs[1].whi};
-            int off[16];
-            float wt[16];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rb = __mul24(yr[r], row_stride);
-                const int sw = rap_swz(yr[r]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    off[r * 4 + c] = (xc[c] ^ sw) + rb;
-                    wt[r * 4 + c] = rw[r] * cw[c];
-                }
-            }
-            if (GT) {
-#pragma unroll
-                for (int g = 0; g < (GT ? GT : 1); ++g) {
-                    const float4 *pl = s_plane + g * WS; // immediate offset when WST != 0
-                    f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
-                    float *og = o + (4 * g) * 49; // immediate store offsets
-                    og[0] = lo.x;
-                    og[49] = lo.y;
-                    og[98] = hi.x;
-                    og[147] = hi.y;
-                }
+            // the 1/4 of the 2x2 average is folded into the row weights (exact: power of two);
+            // the 3-tap forms are chosen per wave so that the branch is uniform
+            const bool y3 = __all(axis_mergeable(ys[0], ys[1]));
+            const bool x3 = __all(axis_mergeable(xs[0], xs[1]));
+            if (y3) {
+                const AxisTaps ty = axis_taps3(ys[0], ys[1], 0.25f, H);
+                if (x3)
+                    rap_item<3, 3, GT>(s_plane, WS, row_stride, G, nc, ty, axis_taps3(xs[0], xs[1], 1.0f, W), o);
+                else
+                    rap_item<3, 4, GT>(s_plane, WS, row_stride, G, nc, ty, axis_taps4(xs[0], xs[1], 1.0f), o);
             } else {
-                for (int g = 0; g < G; ++g) {
-                    const float4 *pl = s_plane + g * WS;
-                    f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
-                    float *og = o + (4 * g) * 49;
-                    og[0] = lo.x;
-                    if (4 * g + 1 < nc) og[49] = lo.y;
-                    if (4 * g + 2 < nc) og[98] = hi.x;
-                    if (4 * g + 3 < nc) og[147] = hi.y;
-                }
+                const AxisTaps ty = axis_taps4(ys[0], ys[1], 0.25f);
+                if (x3)
+                    rap_item<4, 3, GT>(s_plane, WS, row_stride, G, nc, ty, axis_taps3(xs[0], xs[1], 1.0f, W), o);
+                else
+                    rap_item<4, 4, GT>(s_plane, WS, row_stride, G, nc, ty, axis_taps4(xs[0], xs[1], 1.0f), o);
             }
         }
     }
