@@ -224,8 +224,9 @@ extern "C" int frcnn_roi_align_f32(const float *feat, int B, int C, int H, int W
 // ([group][pixel] of float4), then sweeps its RoIs.  A lane produces one (RoI, 4 channels, bin)
 // item: 2x2 bilinear samples x 4 taps, each tap ONE ds_read_b128 that serves 4 channels, i.e. the
 // 16 taps per output come from LDS (256 B/clk/CU) instead of the vector L1 (64 B/clk/CU), and HBM
-// sees the feature map once plus the output stream.  Lanes run over bins fastest, so each of the
-// four stores of an item lands in a 196-byte contiguous run of the (K, C, 7, 7) output.
+// sees the feature map once plus the output stream.  A wave takes one whole RoI at a time with
+// lane = bin, so each channel store is one 196-byte run and the 16 stores of an iteration fill a
+// contiguous 3136-byte piece of the (K, C, 7, 7) output.
 
 __device__ __forceinline__ int map_level(float4 p, int k_min, int k_max)
 {
@@ -377,10 +378,12 @@ __device__ __forceinline__ void rap_item(const float4 *s_plane, int WS, int row_
     }
 }
 
-// The profile that shaped this kernel (rocprofv3 PMC, MI355X): it is bound by vector-instruction
-// ISSUE (about 5 cycles per wave instruction, 65 % of all SIMD cycles issuing), not by LDS
-// bandwidth, HBM or the store path -- so everything that is not one of the 32 packed FMAs per
-// (item, channel group) is hoisted out of the group loop or folded into an immediate.
+// What bounds this kernel (A/B builds on MI355X, batch 16 x 2000 RoIs, C = 512; DESIGN.md has the
+// table): the OUTPUT STORE STREAM.  With the arithmetic removed the stores alone take 0.77 ms of
+// the 0.91 ms; the arithmetic alone (LDS taps + packed FMAs + per-item set-up) takes 0.66 ms and
+// overlaps with them only in part.  How the 3.2 GB are handed to the memory system matters more
+// than anything computed here: the same bytes written as 64-item slices that straddle RoIs took
+// 1.07 ms, as whole (RoI, chunk) pieces per wave 0.77 ms (tools/store_probe.hip).
 // GT  = channel groups per chunk known at compile time (4 = a full 16-channel chunk) or 0.
 // WST = compile-time LDS row stride in pixels (64 covers W <= 64) or 0 for a runtime stride.
 template <int GT, int WST>
