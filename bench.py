@@ -105,6 +105,10 @@ class Path:
         self.ag = AnchorGenerator()
         self.pool = ROIPooling(['1'], [7, 7], 2)
         self.textbook = textbook
+        # two HIP streams: the proposal stages (a few single-workgroup-per-image kernels that leave most
+        # of the chip idle) of batch i+1 run while RoIAlign (the whole chip, store-bound) of batch i drains
+        self.s_prop = torch.cuda.Stream(device=dev, priority=-1)  # its small kernels take freed CUs first
+        self.s_roi = torch.cuda.Stream(device=dev)
 
     def anchors(self, batch, feat):
         return torch.cat([a[0].reshape(-1, 4) for a in self.ag((batch, IMG_H, IMG_W), [feat])], 0)
@@ -131,6 +135,40 @@ class Path:
         mark("gather")
         out, total = self.pool.forward_padded({'1': feat}, props, n_keep, [(IMG_H, IMG_W)])
         mark("roi_align")
+        return props, n_keep, out, total
+
+    def step_pipelined(self, anchors, cls, reg, feat, ev=None):
+        """Same work as step(); proposal stages on s_prop, RoIAlign on s_roi behind an event, so that
+        consecutive steps overlap (software pipeline of depth 2 over batches)."""
+        ops = self.ops
+
+        def mark(name, stream):
+            if ev is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                ev.append((name, e))
+
+        with torch.cuda.stream(self.s_prop):
+            mark("start", self.s_prop)
+            scores, deltas = ops.rpn_flatten([cls], [reg])
+            mark("flatten", self.s_prop)
+            top_val, top_idx = ops.topk_desc(scores, PRE_NMS)
+            mark("topk", self.s_prop)
+            boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
+            mark("decode_clip_filter", self.s_prop)
+            keep, n_keep = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
+            mark("nms", self.s_prop)
+            props = ops.gather_boxes(boxes, keep, n_keep)
+            mark("gather", self.s_prop)
+            ready = torch.cuda.Event()
+            ready.record(self.s_prop)
+        with torch.cuda.stream(self.s_roi):
+            self.s_roi.wait_event(ready)
+            props.record_stream(self.s_roi)
+            n_keep.record_stream(self.s_roi)
+            mark("roi_queue_wait", self.s_roi)
+            out, total = self.pool.forward_padded({'1': feat}, props, n_keep, [(IMG_H, IMG_W)])
+            mark("roi_align", self.s_roi)
         return props, n_keep, out, total
 
 
@@ -160,8 +198,9 @@ def cpu_baseline(batch_sample, threads, workload):
                        "OpenMP (RoIAlign, IoU rows), %.2f s, %d RoIs" % (batch_sample, C, dt, rois))
 
 
-def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup):
+def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipelined=True):
     """Warm up, then time exactly `steps` steps between barrier+synchronize pairs; max over ranks."""
+    step = path.step_pipelined if pipelined else path.step
     cls, reg, feat = (t.to(dev) for t in make_batch(rank * B, B, workload))
     anchors = path.anchors(B, feat)
 
@@ -172,13 +211,13 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup):
         torch.cuda.synchronize()
 
     for _ in range(warmup):
-        path.step(anchors, cls, reg, feat)
+        step(anchors, cls, reg, feat)
     barrier()
     events = []
     t0 = time.perf_counter()
     for _ in range(steps):
         ev = []
-        props, n_keep, out, total = path.step(anchors, cls, reg, feat, ev)
+        props, n_keep, out, total = step(anchors, cls, reg, feat, ev)
         events.append(ev)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -191,6 +230,7 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup):
         for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
             stage_ms.setdefault(n1, []).append(e0.elapsed_time(e1))
     stage_ms = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+    queue_wait = stage_ms.pop("roi_queue_wait", None)  # time RoIAlign of step i waited behind that of step i-1
     counts = n_keep.tolist()
     n_rois = int(total.item())
     ms_per_step = elapsed / steps * 1e3
@@ -200,6 +240,7 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup):
     rest_bytes = B * (A * 4 + PRE_NMS * 8 + PRE_NMS * 32 + PRE_NMS * 20 + PRE_NMS * 20 + POST_NMS * 24)
     ra_ms = stage_ms["roi_align"]
     res = dict(workload=workload, value=world * B * steps / elapsed, ms_per_step=ms_per_step, stage_ms=stage_ms,
+               roi_queue_wait_ms=queue_wait,
                proposals_per_image_mean=float(np.mean(counts)), rois_per_step=n_rois,
                path_algorithmic_bytes_per_step=roi_bytes + rest_bytes,
                path_hbm_frac=(roi_bytes + rest_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -219,6 +260,8 @@ def main():
     ap.add_argument("--workload", choices=["realistic", "gaussian"], default="realistic")
     ap.add_argument("--cpu-sample", type=int, default=4, help="images timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workload and NMS microbenchmarks")
+    ap.add_argument("--serial", action="store_true",
+                    help="one stream, no overlap between consecutive steps (the pipelined form is the default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -238,7 +281,8 @@ def main():
     _lib.load()
     path = Path(dev)
     B = args.batch
-    main_res, props, n_keep = run_workload(path, dev, dist, rank, world, B, args.workload, args.steps, args.warmup)
+    main_res, props, n_keep = run_workload(path, dev, dist, rank, world, B, args.workload, args.steps, args.warmup,
+                                           pipelined=not args.serial)
 
     # final gather of per-image proposals over RCCL (outside the timed region)
     gather_ms = None
@@ -254,9 +298,12 @@ def main():
     extras = {}
     if not args.no_extras and world == 1:
         other = "gaussian" if args.workload == "realistic" else "realistic"
-        sec, _, _ = run_workload(path, dev, None, 0, 1, B, other, max(5, args.steps // 5), 2)
+        sec, _, _ = run_workload(path, dev, None, 0, 1, B, other, max(5, args.steps // 5), 2, pipelined=not args.serial)
         sec.pop("roofline")
         extras["secondary_workload"] = sec
+        if not args.serial:  # the same steps one after another on one stream: per-batch latency, stage times
+            ser, _, _ = run_workload(path, dev, None, 0, 1, B, args.workload, max(5, args.steps // 2), 2, pipelined=False)
+            extras["serial"] = {k: ser[k] for k in ("value", "ms_per_step", "stage_ms")}
         extras.update(nms_microbench(path, dev))
 
     if rank == 0:
@@ -272,9 +319,12 @@ def main():
                                    "reference (bug-compatible) decode, %s"
                                    % (B, A, PRE_NMS, NMS_THR, POST_NMS, C, desc[args.workload]),
                        "batch_per_gpu": B, "parallelism": "image-sharded x%d" % world,
+                       "pipelining": "none (one stream)" if args.serial else
+                       "2 HIP streams: proposal stages of batch i+1 overlap RoIAlign of batch i",
                        "proposals_per_image_mean": main_res["proposals_per_image_mean"],
                        "rois_per_step": main_res["rois_per_step"]},
             "stage_ms": main_res["stage_ms"],
+            "roi_queue_wait_ms": main_res["roi_queue_wait_ms"],
             "path_algorithmic_bytes_per_step": main_res["path_algorithmic_bytes_per_step"],
             "path_hbm_frac": main_res["path_hbm_frac"],
             "roofline": main_res["roofline"],
