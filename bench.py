@@ -107,8 +107,8 @@ class Path:
         self.textbook = textbook
         # two HIP streams: the proposal stages (a few single-workgroup-per-image kernels that leave most
         # of the chip idle) of batch i+1 run while RoIAlign (the whole chip, store-bound) of batch i drains
-        self.s_prop = torch.cuda.Stream(device=dev, priority=-1)  # its small kernels take freed CUs first
-        self.s_roi = torch.cuda.Stream(device=dev)
+        from objectdetection_amd.pipeline import ProposalRoIPipeline
+        self.pipe = ProposalRoIPipeline(dev)
 
     def anchors(self, batch, feat):
         return torch.cat([a[0].reshape(-1, 4) for a in self.ag((batch, IMG_H, IMG_W), [feat])], 0)
@@ -138,9 +138,9 @@ class Path:
         return props, n_keep, out, total
 
     def step_pipelined(self, anchors, cls, reg, feat, ev=None):
-        """Same work as step(); proposal stages on s_prop, RoIAlign on s_roi behind an event, so that
-        consecutive steps overlap (software pipeline of depth 2 over batches)."""
-        ops = self.ops
+        """Same work as step(); proposal stages and RoIAlign on the two streams of ProposalRoIPipeline,
+        so that consecutive steps overlap (software pipeline of depth 2 over batches)."""
+        ops, pipe = self.ops, self.pipe
 
         def mark(name, stream):
             if ev is not None:
@@ -148,27 +148,27 @@ class Path:
                 e.record(stream)
                 ev.append((name, e))
 
-        with torch.cuda.stream(self.s_prop):
-            mark("start", self.s_prop)
+        def proposals():
+            mark("start", pipe.s_prop)
             scores, deltas = ops.rpn_flatten([cls], [reg])
-            mark("flatten", self.s_prop)
+            mark("flatten", pipe.s_prop)
             top_val, top_idx = ops.topk_desc(scores, PRE_NMS)
-            mark("topk", self.s_prop)
+            mark("topk", pipe.s_prop)
             boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
-            mark("decode_clip_filter", self.s_prop)
+            mark("decode_clip_filter", pipe.s_prop)
             keep, n_keep = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
-            mark("nms", self.s_prop)
+            mark("nms", pipe.s_prop)
             props = ops.gather_boxes(boxes, keep, n_keep)
-            mark("gather", self.s_prop)
-            ready = torch.cuda.Event()
-            ready.record(self.s_prop)
-        with torch.cuda.stream(self.s_roi):
-            self.s_roi.wait_event(ready)
-            props.record_stream(self.s_roi)
-            n_keep.record_stream(self.s_roi)
-            mark("roi_queue_wait", self.s_roi)
-            out, total = self.pool.forward_padded({'1': feat}, props, n_keep, [(IMG_H, IMG_W)])
-            mark("roi_align", self.s_roi)
+            mark("gather", pipe.s_prop)
+            return props, n_keep
+
+        def roi(props, n_keep):
+            mark("roi_queue_wait", pipe.s_roi)
+            res = self.pool.forward_padded({'1': feat}, props, n_keep, [(IMG_H, IMG_W)])
+            mark("roi_align", pipe.s_roi)
+            return res
+
+        props, n_keep, (out, total) = pipe.submit(proposals, roi)
         return props, n_keep, out, total
 
 

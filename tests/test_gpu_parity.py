@@ -544,3 +544,49 @@ def test_determinism(dev):
     v1, i1 = ops.topk_desc(s, 5000)
     v2, i2 = ops.topk_desc(s, 5000)
     assert torch.equal(i1, i2) and torch.equal(v1, v2)
+
+
+def test_two_stream_pipeline_matches_serial(dev):
+    """ProposalRoIPipeline (two batches in flight on two streams) returns, bit for bit, what the same
+    stages give when run one after the other on one stream -- over consecutive, different batches, so
+    that a missing event or an early buffer reuse would show."""
+    from objectdetection_amd import ops
+    from objectdetection_amd.pipeline import ProposalRoIPipeline
+    from objectdetection_amd.RPN.anchor_generator import AnchorGenerator
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    B, Himg, Wimg, fh, fw, C = 3, 256, 320, 16, 20, 24
+    rng = np.random.default_rng(5)
+    ag, pool = AnchorGenerator(), ROIPooling(['1'], [7, 7], 2)
+    batches = []
+    for _ in range(4):
+        list_cls, list_regs = synth_head_outputs(rng, B, [(fh, fw)])
+        feat = T(rng.standard_normal((B, C, fh, fw)).astype(np.float32), dev)
+        batches.append((T(list_cls[0], dev), T(list_regs[0], dev), feat))
+    anchors = torch.cat([a[0].reshape(-1, 4) for a in ag((B, Himg, Wimg), [batches[0][2]])], 0)
+
+    def proposals(cls, reg):
+        scores, deltas = ops.rpn_flatten([cls], [reg])
+        top_val, top_idx = ops.topk_desc(scores, 1000)
+        boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, Himg, Wimg, 1e-3)
+        keep, n_keep = ops.nms_sorted(boxes, count, 0.7, 300)
+        return ops.gather_boxes(boxes, keep, n_keep), n_keep
+
+    serial = []
+    for cls, reg, feat in batches:
+        props, n_keep = proposals(cls, reg)
+        out, total = pool.forward_padded({'1': feat}, props, n_keep, [(Himg, Wimg)])
+        torch.cuda.synchronize()
+        serial.append((props.cpu().numpy(), n_keep.cpu().numpy(), out[:int(total)].cpu().numpy()))
+
+    pipe = ProposalRoIPipeline(dev)
+    pipe.wait_for_current()
+    got = []
+    for cls, reg, feat in batches:  # no synchronisation between submits
+        got.append(pipe.submit(lambda cls=cls, reg=reg: proposals(cls, reg),
+                               lambda p, n, feat=feat: pool.forward_padded({'1': feat}, p, n, [(Himg, Wimg)])))
+    pipe.synchronize()
+    for (props, n_keep, (out, total)), (rp, rn, ro) in zip(got, serial):
+        assert np.array_equal(n_keep.cpu().numpy(), rn)
+        assert_bits_equal(props.cpu().numpy(), rp)
+        assert int(total) == ro.shape[0] and ro.shape[0] > 0
+        assert_bits_equal(out[:int(total)].cpu().numpy(), ro)
