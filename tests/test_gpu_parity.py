@@ -378,6 +378,27 @@ def test_multiscale_roi_align_vs_oracle(dev, oracle):
     np.testing.assert_allclose(got_rev.cpu().numpy(), ref_rev, rtol=RTOL, atol=1e-5)
 
 
+def test_multiscale_roi_align_config5_scale(dev, oracle):
+    """SURVEY 8d config 5 shapes: C = 256, pyramid 100x168 .. 13x21 on an 800x1344 image, 2,000 RoIs.
+    The 100x168 level is too large for the LDS-resident kernel and takes the direct path."""
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    rng = np.random.default_rng(23)
+    B, C, Himg, Wimg = 1, 256, 800, 1344
+    fsz = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for h, w in fsz]
+    props = [realistic_boxes(rng, 2000, Wimg, Himg)]
+    props[0][:40, :2] = rng.uniform(0, 300, (40, 2))          # some large boxes for the coarsest level
+    props[0][:40, 2:] = props[0][:40, :2] + rng.uniform(460, 500, (40, 2))
+    props[0][40:50] = np.concatenate([rng.uniform(0, 20, (10, 2)), rng.uniform(0, 20, (10, 2)) + [1300, 760]], 1)
+    ref, ref_lvl = oracle.multiscale_roi_align(feats, props, [(Himg, Wimg)], (7, 7), 2)
+    assert len(np.unique(ref_lvl)) == 4
+    pool = ROIPooling(['1', '2', '3', '4'], [7, 7], 2)
+    d = {str(i + 1): T(f, dev) for i, f in enumerate(feats)}
+    out, total = pool.forward_padded(d, T(np.stack(props), dev), T([2000], dev, torch.int32), [(Himg, Wimg)])
+    assert int(total) == 2000
+    np.testing.assert_allclose(out[:2000].cpu().numpy(), ref, rtol=RTOL, atol=1e-5)
+
+
 def test_roi_pool_max_vs_oracle(dev, oracle):
     from objectdetection_amd import ops
     rng = np.random.default_rng(11)
@@ -415,7 +436,9 @@ class _FixedHead(torch.nn.Module):
 
 
 @pytest.mark.parametrize("info,fsz,pre,post", [((2, 600, 1000), [(37, 62)], 12000, 2000),
-                                               ((2, 256, 256), [(112, 112), (64, 64), (32, 32)], 2000, 2000)])
+                                               ((2, 256, 256), [(112, 112), (64, 64), (32, 32)], 2000, 2000),
+                                               # A = 200,907 anchors, k = 30,000
+                                               ((1, 800, 1344), [(13, 21), (25, 42), (50, 84), (100, 168)], 30000, 2000)])
 def test_rpn_forward_vs_oracle(dev, oracle, info, fsz, pre, post):
     """RPN.forward (eval) end to end.  Stages are compared on identical inputs: the oracle's NMS is
     fed the HIP path's decoded boxes, so libm-vs-device exp ULPs cannot flip a keep decision."""
