@@ -66,6 +66,12 @@ int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, float *val_out
 int frcnn_box_regression_f32(const float *box, const float *regs, int n, int K, float *out,
                              void *stream);
 
+/* Backward of the decode above: what torch autograd produces through utils.py:173-208 (the
+ * reference keeps its proposals on the autograd graph, RPN/rpn.py:75,85).  grad_out, grad_regs:
+ * (n,4K); grad_box: (n,4) or NULL.  The clamp passes the gradient where dw <= log(1000/16). */
+int frcnn_box_regression_backward_f32(const float *box, const float *regs, const float *grad_out,
+                                      int n, int K, float *grad_regs, float *grad_box, void *stream);
+
 /* utils.py:242-259 (box_clip): x to [0,image_w], y to [0,image_h] (inclusive). */
 int frcnn_box_clip_f32(const float *box, int n, float image_h, float image_w, float *out,
                        void *stream);

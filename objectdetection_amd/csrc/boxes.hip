@@ -123,6 +123,53 @@ extern "C" int frcnn_box_regression_f32(const float *box, const float *regs, int
     return FRCNN_OK;
 }
 
+// Backward of decode (utils.py:173-208 under torch autograd; the reference never detaches its
+// proposals, rpn.py:75,85).  One thread per box row, looping over its K delta groups so that the
+// box gradient (a sum over K) needs no atomics.  torch.clamp(max=) passes the gradient where
+// dw <= max (equality included).
+__global__ void __launch_bounds__(256) box_regression_backward_kernel(
+    const float4 *__restrict__ box, const float4 *__restrict__ regs, const float4 *__restrict__ grad_out, int n,
+    int K, float4 *__restrict__ grad_regs, float4 *__restrict__ grad_box)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float clampv = (float)FRCNN_DW_CLAMP;
+    const float4 b = box[i];
+    const float bw = b.z - b.x, bh = b.w - b.y;
+    float gbw = 0.0f, gbh = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const float4 r = regs[(long long)i * K + k];
+        const float4 g = grad_out[(long long)i * K + k];
+        const float dwc = r.z > clampv ? clampv : r.z;
+        const float dhc = r.w > clampv ? clampv : r.w;
+        const float ew = expf(dwc), eh = expf(dhc);
+        const float gpx = g.x + g.z, gpy = g.y + g.w;               // through box_x / box_y
+        const float gpw = g.z / 2.0f - g.x / 2.0f, gph = g.w / 2.0f - g.y / 2.0f; // through box_w/2, box_h/2
+        float4 gr;
+        gr.x = gpx * bw;
+        gr.y = gpy * bh;
+        gr.z = r.z <= clampv ? (gpw * bw) * ew : 0.0f;
+        gr.w = r.w <= clampv ? (gph * bh) * eh : 0.0f;
+        grad_regs[(long long)i * K + k] = gr;
+        gbw += gpx / 2.0f + gpx * r.x + gpw * ew;
+        gbh += gpy / 2.0f + gpy * r.y + gph * eh;
+    }
+    if (grad_box) grad_box[i] = make_float4(-gbw, -gbh, gbw, gbh);
+}
+
+extern "C" int frcnn_box_regression_backward_f32(const float *box, const float *regs, const float *grad_out,
+                                                 int n, int K, float *grad_regs, float *grad_box, void *stream)
+{
+    FRCNN_REQUIRE(n >= 0 && K > 0, "box_regression_backward: bad shape");
+    if (n == 0) return FRCNN_OK;
+    FRCNN_REQUIRE(box && regs && grad_out && grad_regs, "box_regression_backward: null pointer");
+    hipLaunchKernelGGL(box_regression_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)box, (const float4 *)regs, (const float4 *)grad_out, n, K,
+                       (float4 *)grad_regs, (float4 *)grad_box);
+    FRCNN_CHECK_LAUNCH("box_regression_backward");
+    return FRCNN_OK;
+}
+
 __global__ void __launch_bounds__(256) box_clip_kernel(const float4 *__restrict__ box, int n,
                                                        float image_h, float image_w,
                                                        float4 *__restrict__ out)

@@ -129,6 +129,41 @@ def box_regression(box, regs):
     return out
 
 
+def box_regression_backward(box, regs, grad_out, want_box_grad=True):
+    """-> (grad_regs (n,4K), grad_box (n,4) or None): torch autograd's result through utils.py:173-208."""
+    _need_gpu(box, regs, grad_out)
+    box, regs, grad_out = _f32c(box), _f32c(regs), _f32c(grad_out)
+    n = box.shape[0]
+    if regs.shape != grad_out.shape or regs.shape[0] != n or regs.shape[1] % 4:
+        raise ValueError("box_regression_backward: shapes %s %s %s" % (tuple(box.shape), tuple(regs.shape),
+                                                                        tuple(grad_out.shape)))
+    K = regs.shape[1] // 4
+    grad_regs = torch.empty_like(regs)
+    grad_box = torch.empty_like(box) if want_box_grad else None
+    with torch.cuda.device(box.device):
+        rc = _lib.load().frcnn_box_regression_backward_f32(_ptr(box), _ptr(regs), _ptr(grad_out), n, K,
+                                                           _ptr(grad_regs), _ptr(grad_box) if want_box_grad else None,
+                                                           _stream())
+    _lib.check(rc, "box_regression_backward")
+    return grad_regs, grad_box
+
+
+class BoxRegression(torch.autograd.Function):
+    """Differentiable decode: forward and backward are the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, box, regs):
+        ctx.save_for_backward(box, regs)
+        return box_regression(box.detach(), regs.detach())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        box, regs = ctx.saved_tensors
+        need_box = ctx.needs_input_grad[0]
+        grad_regs, grad_box = box_regression_backward(box.detach(), regs.detach(), grad_out, need_box)
+        return (grad_box if need_box else None), (grad_regs if ctx.needs_input_grad[1] else None)
+
+
 def box_clip(box, image_h, image_w):
     _need_gpu(box)
     box = _f32c(box)

@@ -4,7 +4,8 @@ the gfx950 kernels.  Each function cites the reference lines it replaces.
 Divergences from the reference, on purpose (SURVEY.md 8a, quirk register):
   * results live on the inputs' HIP device (the reference leaks CPU tensors, quirk Q6:
     utils.py:275,168,310-311 -- its target path only works on CPU);
-  * outputs are detached (the kernels are not differentiable);
+  * outputs are detached (the kernels are not differentiable), except box_regression, which has a
+    HIP backward (SURVEY.md 8f row 4);
   * CPU tensors are rejected: there is no CPU fallback.
 Everything else is bug-compatible, including quirk Q1 (box_regression ignores the box origin).
 """
@@ -34,7 +35,11 @@ def box_deviation(box_1, box_2, weights=None):
 
 
 def box_regression(box, regression_params):
-    """utils.py:173-208 -- decode (n,4K) deltas against (n,4) boxes; centre = (w/2, h/2) (Q1)."""
+    """utils.py:173-208 -- decode (n,4K) deltas against (n,4) boxes; centre = (w/2, h/2) (Q1).
+    Differentiable like the reference's (which keeps proposals on the graph, rpn.py:75,85): when an
+    input requires grad the result carries a HIP backward (ops.BoxRegression)."""
+    if torch.is_grad_enabled() and (box.requires_grad or regression_params.requires_grad):
+        return ops.BoxRegression.apply(box, regression_params)
     return ops.box_regression(box, regression_params)
 
 

@@ -222,6 +222,42 @@ void orc_box_regression(const float *box, const float *regs, int n, int K, float
     }
 }
 
+/* Backward of utils.py:173-208 as torch autograd evaluates it (grad of each forward op in turn).
+ * grad_out (n,4K) -> grad_regs (n,4K), grad_box (n,4) (may be NULL).  torch.clamp(max=) passes the
+ * gradient where the input <= max. */
+void orc_box_regression_backward(const float *box, const float *regs, const float *grad_out, int n,
+                                 int K, float *grad_regs, float *grad_box)
+{
+    const float clampv = (float)log(1000.0 / 16.0);
+    for (int i = 0; i < n; ++i) {
+        float bw = box[4 * i + 2] - box[4 * i + 0];
+        float bh = box[4 * i + 3] - box[4 * i + 1];
+        float gbw = 0.0f, gbh = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float *r = regs + (size_t)i * 4 * K + 4 * k;
+            const float *g = grad_out + (size_t)i * 4 * K + 4 * k;
+            float *o = grad_regs + (size_t)i * 4 * K + 4 * k;
+            float dwc = r[2] > clampv ? clampv : r[2];
+            float dhc = r[3] > clampv ? clampv : r[3];
+            float ew = expf(dwc), eh = expf(dhc);
+            float gpx = g[0] + g[2], gpy = g[1] + g[3];
+            float gpw = g[2] / 2.0f - g[0] / 2.0f, gph = g[3] / 2.0f - g[1] / 2.0f;
+            o[0] = gpx * bw;
+            o[1] = gpy * bh;
+            o[2] = r[2] <= clampv ? (gpw * bw) * ew : 0.0f;
+            o[3] = r[3] <= clampv ? (gph * bh) * eh : 0.0f;
+            gbw += gpx / 2.0f + gpx * r[0] + gpw * ew;
+            gbh += gpy / 2.0f + gpy * r[1] + gph * eh;
+        }
+        if (grad_box) {
+            grad_box[4 * i + 0] = -gbw;
+            grad_box[4 * i + 1] = -gbh;
+            grad_box[4 * i + 2] = gbw;
+            grad_box[4 * i + 3] = gbh;
+        }
+    }
+}
+
 /* utils.py:242-259: x in clamp[0, image_w], y in clamp[0, image_h] (inclusive bounds). */
 void orc_box_clip(const float *box, int n, float image_h, float image_w, float *out)
 {

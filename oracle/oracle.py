@@ -159,6 +159,19 @@ def box_regression(box, regs):
     return out
 
 
+def box_regression_backward(box, regs, grad_out):
+    """-> (grad_regs, grad_box): the reference's autograd through utils.py:173-208."""
+    box, regs, grad_out = _f32(box).reshape(-1, 4), _f32(regs), _f32(grad_out)
+    n = box.shape[0]
+    regs, grad_out = regs.reshape(n, -1), grad_out.reshape(n, -1)
+    K = regs.shape[1] // 4
+    grad_regs = np.empty((n, 4 * K), np.float32)
+    grad_box = np.empty((n, 4), np.float32)
+    lib().orc_box_regression_backward(_fp(box), _fp(regs), _fp(grad_out), ctypes.c_int(n), ctypes.c_int(K),
+                                      _fp(grad_regs), _fp(grad_box))
+    return grad_regs, grad_box
+
+
 def box_clip(box, image_size):
     box = _f32(box).reshape(-1, 4)
     h, w = image_size

@@ -12,6 +12,8 @@ reference's own functions produced for them:
                                            box_deviation              -> targets.npz
   code/FasterRCNN/utils.py                 box_regression / box_clip /
                                            remove_small_box           -> decode.npz
+  code/FasterRCNN/utils.py                 box_regression, backward
+                                           (torch autograd through it) -> decode_grad.npz
   code/FasterRCNN/utils.py                 get_sampling_factor        -> sampling.npz
   RPN/rpn.py:55-83 call sequence replayed with the reference's utils
   functions and torch.topk (rpn.py itself cannot be imported: it needs
@@ -189,6 +191,37 @@ def gen_decode():
     save("decode.npz", **out)
 
 
+def gen_decode_grad():
+    """Gradients the reference's own autograd produces through utils.box_regression (utils.py:173-208):
+    the reference never detaches its proposals (rpn.py:75,85), so decode is on its backward path."""
+    g = torch.Generator().manual_seed(4242)
+    out = {}
+    for K in (1, 3):
+        n = 512
+        xy = torch.rand(n, 2, generator=g) * 400
+        wh = torch.rand(n, 2, generator=g) * 300 + 1
+        box = torch.cat([xy, xy + wh], 1).requires_grad_(True)
+        regs = torch.randn(n, 4 * K, generator=g)
+        regs[:, 0::4] *= 0.1
+        regs[:, 1::4] *= 0.1
+        regs[:, 2::4] *= 0.2
+        regs[:, 3::4] *= 0.2
+        regs[0, 2::4] = 9.0                      # above the clamp: no gradient to dw
+        regs[1, 3::4] = 4.135166556742356        # fp32(log(1000/16)) rounds just above the clamp
+        regs[2, 2::4] = 4.0                      # below the clamp
+        regs[3, :] = 0.0
+        regs = regs.requires_grad_(True)
+        upstream = torch.randn(n, 4 * K, generator=g)
+        dec = R.box_regression(box, regs)
+        dec.backward(upstream)
+        out[f"k{K}.box"] = box.detach().numpy()
+        out[f"k{K}.regs"] = regs.detach().numpy()
+        out[f"k{K}.upstream"] = upstream.numpy()
+        out[f"k{K}.grad_regs"] = regs.grad.numpy()
+        out[f"k{K}.grad_box"] = box.grad.numpy()
+    save("decode_grad.npz", **out)
+
+
 def gen_sampling():
     out = {}
     cases = [(256, 0.5, 40, 18000), (256, 0.5, 300, 18000), (128, 0.25, 10, 1500), (512, 0.25, 0, 60),
@@ -265,5 +298,6 @@ if __name__ == "__main__":
     gen_anchors()
     gen_targets()
     gen_decode()
+    gen_decode_grad()
     gen_sampling()
     gen_rpn_stages()

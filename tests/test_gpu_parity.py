@@ -142,6 +142,29 @@ def test_box_regression_golden(dev, K):
     np.testing.assert_allclose(out, g[f"k{K}.decoded"], rtol=RTOL, atol=1e-4)
 
 
+@pytest.mark.parametrize("K", [1, 3])
+def test_box_regression_backward_golden(dev, oracle, K):
+    """decode is differentiable like the reference's; gradients match what the
+    reference's own autograd produced (decode_grad.npz) and the CPU restatement."""
+    from objectdetection_amd import utils as U
+    g = load_golden("decode_grad.npz")
+    box = T(g[f"k{K}.box"], dev).requires_grad_(True)
+    regs = T(g[f"k{K}.regs"], dev).requires_grad_(True)
+    out = U.box_regression(box, regs)
+    assert out.requires_grad
+    out.backward(T(g[f"k{K}.upstream"], dev))
+    np.testing.assert_allclose(regs.grad.cpu().numpy(), g[f"k{K}.grad_regs"], rtol=RTOL, atol=1e-3)
+    np.testing.assert_allclose(box.grad.cpu().numpy(), g[f"k{K}.grad_box"], rtol=RTOL, atol=1e-3)
+    ref_regs, ref_box = oracle.box_regression_backward(g[f"k{K}.box"], g[f"k{K}.regs"], g[f"k{K}.upstream"])
+    np.testing.assert_allclose(regs.grad.cpu().numpy(), ref_regs, rtol=RTOL, atol=1e-4)
+    np.testing.assert_allclose(box.grad.cpu().numpy(), ref_box, rtol=RTOL, atol=1e-4)
+    # only the deltas need a gradient (the RPN case: anchors are constants); no-grad inputs stay on the plain path
+    regs2 = T(g[f"k{K}.regs"], dev).requires_grad_(True)
+    U.box_regression(T(g[f"k{K}.box"], dev), regs2).backward(T(g[f"k{K}.upstream"], dev))
+    assert torch.equal(regs2.grad, regs.grad)
+    assert not U.box_regression(T(g[f"k{K}.box"], dev), T(g[f"k{K}.regs"], dev)).requires_grad
+
+
 def test_clip_small_golden(dev):
     from objectdetection_amd import utils as U
     g = load_golden("decode.npz")

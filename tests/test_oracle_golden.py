@@ -76,6 +76,17 @@ def test_box_regression(oracle, K):
     np.testing.assert_allclose(out, g[f"k{K}.decoded"], rtol=RTOL, atol=1e-4)
 
 
+@pytest.mark.parametrize("K", [1, 3])
+def test_box_regression_backward(oracle, K):
+    """Gradients of the reference's autograd through box_regression (decode_grad.npz)."""
+    g = load_golden("decode_grad.npz")
+    grad_regs, grad_box = oracle.box_regression_backward(g[f"k{K}.box"], g[f"k{K}.regs"], g[f"k{K}.upstream"])
+    np.testing.assert_allclose(grad_regs, g[f"k{K}.grad_regs"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(grad_box, g[f"k{K}.grad_box"], rtol=1e-5, atol=1e-3)
+    assert (g[f"k{K}.grad_regs"][0, 2::4] == 0).all() and (grad_regs[0, 2::4] == 0).all()      # clamped: no gradient
+    assert (g[f"k{K}.grad_regs"][1, 3::4] != 0).all() and (grad_regs[1, 3::4] != 0).all()      # == clamp: passes
+
+
 def test_clip_and_small_filter(oracle):
     g = load_golden("decode.npz")
     h, w = (int(v) for v in g["clip.image_size"])
