@@ -174,6 +174,28 @@ int frcnn_roi_pool_f32(const float *feat, int B, int C, int H, int W, const floa
                        int pooled_h, int pooled_w, float spatial_scale, float *out, int32_t *argmax,
                        void *stream);
 
+/* ---- sampled-gather + losses ---------------------------------------------
+ * RPN/rpn.py:122-137 in one launch: rows `index[s]` (flat b*A+a, S of them, negatives first) are
+ * gathered from scores (rows), regs (rows,4), labels (rows), reg_labels (rows,4);
+ * loss_out[0] = mean BCE-with-logits, loss_out[1] = utils.smooth_l1_loss (utils.py:315-336) with
+ * `beta`, mean over all 4*S elements (quirk Q7: negatives included).  grad_scores (rows) and
+ * grad_regs (rows,4), when not NULL, are zero-filled and receive d loss_out[0] / d scores and
+ * d loss_out[1] / d regs.  An index outside [0, rows) turns both losses into NaN. */
+int frcnn_rpn_sampled_loss_f32(const float *scores, const float *regs, const float *labels,
+                               const float *reg_labels, const int64_t *index, int S, int64_t rows,
+                               float beta, float *loss_out, float *grad_scores, float *grad_regs,
+                               void *stream);
+
+/* ROIHead/roi_head.py:141-152 in one launch.  logits: (N,Kc); pred: (N,Kc,4); cls_label: (N) fp32
+ * class ids (0 = background, truncated like .long()); reg_label: (N,4).
+ * loss_out[0] = mean cross-entropy; loss_out[1] = smooth-L1 mean over the 4*n_pos elements of
+ * pred[n, label_n] - reg_label[n] for rows with label > 0 (NaN when n_pos == 0, as torch's mean of
+ * an empty tensor).  grad_logits (N,Kc), grad_pred (N,Kc,4): written in full when not NULL.
+ * A label outside [0, Kc) turns both losses into NaN (torch raises). */
+int frcnn_roi_loss_f32(const float *logits, const float *pred, const float *cls_label,
+                       const float *reg_label, int N, int Kc, float beta, float *loss_out,
+                       float *grad_logits, float *grad_pred, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

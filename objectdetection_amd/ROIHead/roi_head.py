@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch.nn import Module
 
 from .. import ops
-from ..utils import get_sampling_factor, remove_small_box, smooth_l1_loss
+from ..utils import get_sampling_factor, remove_small_box
 
 
 class ROIHead(Module):
@@ -86,10 +86,8 @@ class ROIHead(Module):
         if self.training:
             cls_label = torch.cat(list_cls_label)
             reg_label = torch.cat(list_reg_label)
-            cls_loss = F.cross_entropy(predict_cls, cls_label.long())
-            pos_index = torch.where(torch.gt(cls_label, 0))[0]
-            pos_index_label = cls_label[pos_index].long()
-            reg_loss = smooth_l1_loss(predict_reg[pos_index, pos_index_label], reg_label[pos_index])
+            # roi_head.py:144-152: cross-entropy, the positives' per-class rows and smooth-L1 in one launch
+            cls_loss, reg_loss = ops.RoiLoss.apply(predict_cls, predict_reg, cls_label, reg_label)
             roi_loss = {"cls_loss": cls_loss, "reg_loss": reg_loss}
         else:
             # roi_head.py:167-229

@@ -11,10 +11,9 @@ returns the padded (B, num_post_nms, 4) tensor and the per-image counts without 
 """
 import torch
 from torch.nn import Module
-from torch.nn import functional as F
 
 from .. import ops
-from ..utils import get_sampling_factor, smooth_l1_loss
+from ..utils import get_sampling_factor
 
 
 class RPN(Module):
@@ -88,7 +87,8 @@ class RPN(Module):
             regs = torch.cat([r.permute(0, 2, 3, 1).flatten(1, 2).reshape(batch_size, -1, 4) for r in list_regs],
                              dim=1)
             labels, reg_labels = self.anchor_targets(anchors, list_targets, device)
-            list_reg_label, list_reg_prediction, list_cls_label, list_cls_prediction = [], [], [], []
+            A = scores.shape[1]
+            list_index = []
             for b in range(batch_size):
                 cls_label = labels[b]
                 neg_index = torch.where(torch.eq(cls_label, 0))[0]                # rpn.py:115
@@ -96,16 +96,9 @@ class RPN(Module):
                 pos_factor, neg_factor = get_sampling_factor(self.num_sample, self.pos_fraction,
                                                              pos_index.size(0), neg_index.size(0))
                 random_index = torch.cat([neg_index[neg_factor.to(device)], pos_index[pos_factor.to(device)]])
-                list_reg_label.append(reg_labels[b][random_index])
-                list_cls_label.append(cls_label[random_index])
-                list_reg_prediction.append(regs[b][random_index])
-                list_cls_prediction.append(scores[b][random_index])
-            reg_label = torch.cat(list_reg_label)
-            reg_y = torch.cat(list_reg_prediction)
-            cls_label = torch.cat(list_cls_label)
-            cls_y = torch.cat(list_cls_prediction)
-            rpn_loss = {
-                "cls_loss": F.binary_cross_entropy_with_logits(cls_y, cls_label),  # rpn.py:136
-                "reg_loss": smooth_l1_loss(reg_y, reg_label),                       # rpn.py:137 (Q7)
-            }
+                list_index.append(random_index + b * A)
+            # rpn.py:123-137: the four gathers, BCE-with-logits and smooth-L1 (Q7) are one launch, with
+            # gradients to the dense head outputs (ops.RpnSampledLoss)
+            cls_loss, reg_loss = ops.RpnSampledLoss.apply(scores, regs, labels, reg_labels, torch.cat(list_index))
+            rpn_loss = {"cls_loss": cls_loss, "reg_loss": reg_loss}
         return list_nms_proposals, rpn_loss

@@ -164,6 +164,85 @@ class BoxRegression(torch.autograd.Function):
         return (grad_box if need_box else None), (grad_regs if ctx.needs_input_grad[1] else None)
 
 
+SMOOTH_L1_BETA = 1.0 / 9  # utils.py:315
+
+
+def rpn_sampled_loss(scores, regs, labels, reg_labels, index, beta=SMOOTH_L1_BETA, want_grad=True):
+    """RPN/rpn.py:122-137 in one launch.  scores/labels: (rows) or (B,A); regs/reg_labels: (..,4);
+    index: flat int64 rows (b*A + a).  -> (loss (2) [cls, reg], grad_scores, grad_regs)."""
+    _need_gpu(scores, regs, labels, reg_labels, index)
+    scores, regs, labels, reg_labels = _f32c(scores), _f32c(regs), _f32c(labels), _f32c(reg_labels)
+    index = index.to(torch.int64).contiguous()
+    rows = scores.numel()
+    if regs.numel() != 4 * rows or labels.numel() != rows or reg_labels.numel() != 4 * rows:
+        raise ValueError("rpn_sampled_loss: inconsistent shapes")
+    loss = torch.empty((2,), dtype=torch.float32, device=scores.device)
+    gs = torch.empty_like(scores) if want_grad else None
+    gr = torch.empty_like(regs) if want_grad else None
+    with torch.cuda.device(scores.device):
+        rc = _lib.load().frcnn_rpn_sampled_loss_f32(_ptr(scores), _ptr(regs), _ptr(labels), _ptr(reg_labels),
+                                                    _ptr(index), index.numel(), rows, float(beta), _ptr(loss),
+                                                    _ptr(gs) if want_grad else None, _ptr(gr) if want_grad else None,
+                                                    _stream())
+    _lib.check(rc, "rpn_sampled_loss")
+    return loss, gs, gr
+
+
+def roi_loss(logits, pred, cls_label, reg_label, beta=SMOOTH_L1_BETA, want_grad=True):
+    """ROIHead/roi_head.py:141-152 in one launch.  logits (N,Kc), pred (N,Kc*4) or (N,Kc,4), cls_label (N) fp32
+    class ids, reg_label (N,4).  -> (loss (2) [cls, reg], grad_logits, grad_pred)."""
+    _need_gpu(logits, pred, cls_label, reg_label)
+    logits, pred, cls_label, reg_label = _f32c(logits), _f32c(pred), _f32c(cls_label), _f32c(reg_label)
+    N, Kc = logits.shape
+    if pred.numel() != N * Kc * 4 or cls_label.numel() != N or reg_label.numel() != N * 4:
+        raise ValueError("roi_loss: inconsistent shapes")
+    loss = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    gl = torch.empty_like(logits) if want_grad else None
+    gp = torch.empty_like(pred) if want_grad else None
+    with torch.cuda.device(logits.device):
+        rc = _lib.load().frcnn_roi_loss_f32(_ptr(logits), _ptr(pred), _ptr(cls_label), _ptr(reg_label), N, Kc,
+                                            float(beta), _ptr(loss), _ptr(gl) if want_grad else None,
+                                            _ptr(gp) if want_grad else None, _stream())
+    _lib.check(rc, "roi_loss")
+    return loss, gl, gp
+
+
+class RpnSampledLoss(torch.autograd.Function):
+    """(cls_loss, reg_loss) of rpn.py:136-137 with gradients to the dense (B,A) scores and (B,A,4) regs."""
+
+    @staticmethod
+    def forward(ctx, scores, regs, labels, reg_labels, index):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        loss, gs, gr = rpn_sampled_loss(scores.detach(), regs.detach(), labels, reg_labels, index, want_grad=need)
+        if need:
+            ctx.save_for_backward(gs, gr)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        gs, gr = ctx.saved_tensors
+        return (gs * g_cls if ctx.needs_input_grad[0] else None, gr * g_reg if ctx.needs_input_grad[1] else None,
+                None, None, None)
+
+
+class RoiLoss(torch.autograd.Function):
+    """(cls_loss, reg_loss) of roi_head.py:144-152 with gradients to the predictor outputs."""
+
+    @staticmethod
+    def forward(ctx, logits, pred, cls_label, reg_label):
+        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        loss, gl, gp = roi_loss(logits.detach(), pred.detach(), cls_label, reg_label, want_grad=need)
+        if need:
+            ctx.save_for_backward(gl, gp)
+        return loss[0], loss[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        gl, gp = ctx.saved_tensors
+        return (gl * g_cls if ctx.needs_input_grad[0] else None, gp * g_reg if ctx.needs_input_grad[1] else None,
+                None, None)
+
+
 def box_clip(box, image_h, image_w):
     _need_gpu(box)
     box = _f32c(box)

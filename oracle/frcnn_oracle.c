@@ -258,6 +258,75 @@ void orc_box_regression_backward(const float *box, const float *regs, const floa
     }
 }
 
+/* utils.py:331-333 element: x = |d|; x < beta ? 0.5 x^2 / beta : x - 0.5 beta; *g = d/d y_hat. */
+static float orc_sl1(float y_hat, float y, float beta, float *g)
+{
+    float d = y_hat - y, x = fabsf(d);
+    if (x < beta) {
+        *g = d / beta;
+        return 0.5f * x * x / beta;
+    }
+    *g = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    return x - 0.5f * beta;
+}
+
+/* RPN/rpn.py:122-137: gather rows index[s] and reduce (sums in double, then fp32 means).
+ * loss[0] = F.binary_cross_entropy_with_logits mean, loss[1] = utils.smooth_l1_loss mean over 4*S
+ * elements.  grad_scores (rows) / grad_regs (rows*4) are zero-filled then accumulated. */
+void orc_rpn_sampled_loss(const float *scores, const float *regs, const float *labels,
+                          const float *reg_labels, const int64_t *index, int S, int64_t rows, float beta,
+                          float *loss, float *grad_scores, float *grad_regs)
+{
+    double cls = 0.0, reg = 0.0;
+    memset(grad_scores, 0, sizeof(float) * (size_t)rows);
+    memset(grad_regs, 0, sizeof(float) * 4 * (size_t)rows);
+    for (int s = 0; s < S; ++s) {
+        int64_t i = index[s];
+        float x = scores[i], y = labels[i];
+        cls += (double)((x > 0.0f ? x : 0.0f) - x * y + log1pf(expf(-fabsf(x))));
+        grad_scores[i] += (1.0f / (1.0f + expf(-x)) - y) / (float)S;
+        for (int c = 0; c < 4; ++c) {
+            float g;
+            reg += (double)orc_sl1(regs[4 * i + c], reg_labels[4 * i + c], beta, &g);
+            grad_regs[4 * i + c] += g / (4.0f * (float)S);
+        }
+    }
+    loss[0] = (float)(cls / S);
+    loss[1] = (float)(reg / (4.0 * S));
+}
+
+/* ROIHead/roi_head.py:141-152: F.cross_entropy mean + smooth-L1 of the positives' per-class rows. */
+void orc_roi_loss(const float *logits, const float *pred, const float *cls_label, const float *reg_label,
+                  int N, int Kc, float beta, float *loss, float *grad_logits, float *grad_pred)
+{
+    double ce = 0.0, reg = 0.0;
+    int npos = 0;
+    for (int n = 0; n < N; ++n) npos += cls_label[n] > 0.0f;
+    memset(grad_pred, 0, sizeof(float) * 4 * (size_t)N * Kc);
+    for (int n = 0; n < N; ++n) {
+        const float *x = logits + (size_t)n * Kc;
+        int li = (int)cls_label[n];
+        float m = x[0];
+        for (int k = 1; k < Kc; ++k) m = x[k] > m ? x[k] : m;
+        float sum = 0.0f;
+        for (int k = 0; k < Kc; ++k) sum += expf(x[k] - m);
+        float lse = m + logf(sum);
+        ce += (double)(lse - x[li]);
+        for (int k = 0; k < Kc; ++k)
+            grad_logits[(size_t)n * Kc + k] = (expf(x[k] - lse) - (k == li ? 1.0f : 0.0f)) / (float)N;
+        if (cls_label[n] > 0.0f) {
+            for (int c = 0; c < 4; ++c) {
+                float g;
+                size_t e = ((size_t)n * Kc + li) * 4 + c;
+                reg += (double)orc_sl1(pred[e], reg_label[4 * n + c], beta, &g);
+                grad_pred[e] = g / (4.0f * (float)npos);
+            }
+        }
+    }
+    loss[0] = (float)(ce / N);
+    loss[1] = npos ? (float)(reg / (4.0 * npos)) : NAN;
+}
+
 /* utils.py:242-259: x in clamp[0, image_w], y in clamp[0, image_h] (inclusive bounds). */
 void orc_box_clip(const float *box, int n, float image_h, float image_w, float *out)
 {

@@ -172,6 +172,29 @@ def box_regression_backward(box, regs, grad_out):
     return grad_regs, grad_box
 
 
+def rpn_sampled_loss(scores, regs, labels, reg_labels, index, beta=1.0 / 9):
+    """rpn.py:122-137 -> (loss (2), grad_scores, grad_regs) with the inputs' shapes."""
+    scores, regs, labels, reg_labels = _f32(scores), _f32(regs), _f32(labels), _f32(reg_labels)
+    index = np.ascontiguousarray(index, np.int64)
+    loss = np.empty(2, np.float32)
+    gs, gr = np.empty_like(scores), np.empty_like(regs)
+    lib().orc_rpn_sampled_loss(_fp(scores), _fp(regs), _fp(labels), _fp(reg_labels),
+                               index.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(index.size),
+                               ctypes.c_int64(scores.size), ctypes.c_float(beta), _fp(loss), _fp(gs), _fp(gr))
+    return loss, gs, gr
+
+
+def roi_loss(logits, pred, cls_label, reg_label, beta=1.0 / 9):
+    """roi_head.py:141-152 -> (loss (2), grad_logits, grad_pred)."""
+    logits, pred, cls_label, reg_label = _f32(logits), _f32(pred), _f32(cls_label), _f32(reg_label)
+    N, Kc = logits.shape
+    loss = np.empty(2, np.float32)
+    gl, gp = np.empty_like(logits), np.empty_like(pred)
+    lib().orc_roi_loss(_fp(logits), _fp(pred), _fp(cls_label), _fp(reg_label), ctypes.c_int(N), ctypes.c_int(Kc),
+                       ctypes.c_float(beta), _fp(loss), _fp(gl), _fp(gp))
+    return loss, gl, gp
+
+
 def box_clip(box, image_size):
     box = _f32(box).reshape(-1, 4)
     h, w = image_size

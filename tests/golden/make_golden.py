@@ -14,6 +14,8 @@ reference's own functions produced for them:
                                            remove_small_box           -> decode.npz
   code/FasterRCNN/utils.py                 box_regression, backward
                                            (torch autograd through it) -> decode_grad.npz
+  code/FasterRCNN/utils.py                 smooth_l1_loss + torch BCE/CE on
+                                           sampled rows, with gradients -> losses.npz
   code/FasterRCNN/utils.py                 get_sampling_factor        -> sampling.npz
   RPN/rpn.py:55-83 call sequence replayed with the reference's utils
   functions and torch.topk (rpn.py itself cannot be imported: it needs
@@ -222,6 +224,62 @@ def gen_decode_grad():
     save("decode_grad.npz", **out)
 
 
+def gen_losses():
+    """the sampled-gather + loss tails of RPN.forward (rpn.py:122-137) and ROIHead.forward
+    (roi_head.py:141-152) -- torch's F.binary_cross_entropy_with_logits / F.cross_entropy and the
+    reference's utils.smooth_l1_loss (beta = 1/9, mean over ALL gathered elements: quirk Q7), with the
+    gradients torch autograd sends back to the dense head outputs."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(9001)
+    out = {}
+    # --- RPN: B images x A anchors, S sampled anchors per image (negatives first, rpn.py:122)
+    B, A, S = 2, 3000, 256
+    scores = (torch.randn(B, A, generator=g) * 3).requires_grad_(True)
+    regs = torch.randn(B, A, 4, generator=g).requires_grad_(True)
+    labels = torch.full((B, A), -1.0)
+    reg_labels = torch.randn(B, A, 4, generator=g) * 0.3
+    reg_labels[0, :50] *= 0.01                       # |x| < beta branch
+    index = []
+    for b in range(B):
+        perm = torch.randperm(A, generator=g)
+        neg, pos = perm[:S - 40 - 10 * b], perm[S - 40 - 10 * b:S]
+        labels[b, neg] = 0.0
+        labels[b, pos] = 1.0
+        index.append(torch.cat([neg, pos]))
+    scores.data[0, index[0][0]] = 40.0               # saturated logits
+    scores.data[0, index[0][1]] = -40.0
+    cls_y = torch.cat([scores[b][index[b]] for b in range(B)])
+    cls_l = torch.cat([labels[b][index[b]] for b in range(B)])
+    reg_y = torch.cat([regs[b][index[b]] for b in range(B)])
+    reg_l = torch.cat([reg_labels[b][index[b]] for b in range(B)])
+    cls_loss = F.binary_cross_entropy_with_logits(cls_y, cls_l)
+    reg_loss = R.smooth_l1_loss(reg_y, reg_l)
+    (cls_loss * 1.5 + reg_loss * 0.75).backward()
+    out.update({"rpn.scores": scores.detach().numpy(), "rpn.regs": regs.detach().numpy(), "rpn.labels": labels.numpy(),
+                "rpn.reg_labels": reg_labels.numpy(),
+                "rpn.index": torch.cat([index[b] + b * A for b in range(B)]).numpy(),
+                "rpn.upstream": np.asarray([1.5, 0.75], np.float32),
+                "rpn.cls_loss": cls_loss.detach().numpy(), "rpn.reg_loss": reg_loss.detach().numpy(),
+                "rpn.grad_scores": scores.grad.numpy(), "rpn.grad_regs": regs.grad.numpy()})
+    # --- RoI head: N sampled proposals, Kc classes (0 = background), per-class regression
+    N, Kc = 384, 21
+    logits = (torch.randn(N, Kc, generator=g) * 2).requires_grad_(True)
+    pred = torch.randn(N, Kc * 4, generator=g).requires_grad_(True)
+    cls_label = torch.zeros(N)
+    pos = torch.randperm(N, generator=g)[:90]
+    cls_label[pos] = torch.randint(1, Kc, (90,), generator=g).float()
+    reg_label = torch.randn(N, 4, generator=g) * 0.5
+    ce = F.cross_entropy(logits, cls_label.long())
+    pi = torch.where(torch.gt(cls_label, 0))[0]
+    rl = R.smooth_l1_loss(pred.view(N, -1, 4)[pi, cls_label[pi].long()], reg_label[pi])
+    (ce * 0.5 + rl * 2.0).backward()
+    out.update({"roi.logits": logits.detach().numpy(), "roi.pred": pred.detach().numpy(), "roi.cls_label": cls_label.numpy(),
+                "roi.reg_label": reg_label.numpy(), "roi.upstream": np.asarray([0.5, 2.0], np.float32),
+                "roi.cls_loss": ce.detach().numpy(), "roi.reg_loss": rl.detach().numpy(),
+                "roi.grad_logits": logits.grad.numpy(), "roi.grad_pred": pred.grad.numpy()})
+    save("losses.npz", **out)
+
+
 def gen_sampling():
     out = {}
     cases = [(256, 0.5, 40, 18000), (256, 0.5, 300, 18000), (128, 0.25, 10, 1500), (512, 0.25, 0, 60),
@@ -299,5 +357,6 @@ if __name__ == "__main__":
     gen_targets()
     gen_decode()
     gen_decode_grad()
+    gen_losses()
     gen_sampling()
     gen_rpn_stages()

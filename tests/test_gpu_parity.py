@@ -577,6 +577,47 @@ def test_roi_head_eval_and_targets(dev, oracle):
     assert set(loss2) == {"cls_loss", "reg_loss"}
 
 
+def test_sampled_losses_golden(dev, oracle):
+    """fused gather + loss kernels against what torch / the reference's smooth_l1_loss
+    produced (losses.npz), gradients through autograd included, and against the CPU restatement."""
+    from objectdetection_amd import ops
+    g = load_golden("losses.npz")
+    scores = T(g["rpn.scores"], dev).requires_grad_(True)
+    regs = T(g["rpn.regs"], dev).requires_grad_(True)
+    cls_loss, reg_loss = ops.RpnSampledLoss.apply(scores, regs, T(g["rpn.labels"], dev), T(g["rpn.reg_labels"], dev),
+                                                  T(g["rpn.index"], dev, torch.int64))
+    np.testing.assert_allclose(cls_loss.item(), g["rpn.cls_loss"], rtol=RTOL)
+    np.testing.assert_allclose(reg_loss.item(), g["rpn.reg_loss"], rtol=RTOL)
+    up = g["rpn.upstream"]
+    (cls_loss * float(up[0]) + reg_loss * float(up[1])).backward()
+    np.testing.assert_allclose(scores.grad.cpu().numpy(), g["rpn.grad_scores"], rtol=RTOL, atol=1e-8)
+    np.testing.assert_allclose(regs.grad.cpu().numpy(), g["rpn.grad_regs"], rtol=RTOL, atol=1e-8)
+    ref_loss, ref_gs, ref_gr = oracle.rpn_sampled_loss(g["rpn.scores"], g["rpn.regs"], g["rpn.labels"],
+                                                       g["rpn.reg_labels"], g["rpn.index"])
+    np.testing.assert_allclose([cls_loss.item(), reg_loss.item()], ref_loss, rtol=RTOL)
+    np.testing.assert_allclose(scores.grad.cpu().numpy(), ref_gs * up[0], rtol=RTOL, atol=1e-8)
+
+    logits = T(g["roi.logits"], dev).requires_grad_(True)
+    pred = T(g["roi.pred"], dev).requires_grad_(True)
+    ce, rl = ops.RoiLoss.apply(logits, pred, T(g["roi.cls_label"], dev), T(g["roi.reg_label"], dev))
+    np.testing.assert_allclose(ce.item(), g["roi.cls_loss"], rtol=RTOL)
+    np.testing.assert_allclose(rl.item(), g["roi.reg_loss"], rtol=RTOL)
+    up = g["roi.upstream"]
+    (ce * float(up[0]) + rl * float(up[1])).backward()
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), g["roi.grad_logits"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), g["roi.grad_pred"], rtol=RTOL, atol=1e-8)
+    # no positive proposal: the regression mean is over an empty set -> NaN, as in torch; CE stays finite
+    loss, _, _ = ops.roi_loss(T(g["roi.logits"], dev), T(g["roi.pred"], dev),
+                              torch.zeros(g["roi.cls_label"].shape[0], device=dev), T(g["roi.reg_label"], dev))
+    assert torch.isfinite(loss[0]) and torch.isnan(loss[1])
+    # an out-of-range sample index poisons the RPN losses instead of reading out of bounds
+    bad = T(g["rpn.index"], dev, torch.int64).clone()
+    bad[3] = g["rpn.scores"].size
+    loss, _, _ = ops.rpn_sampled_loss(T(g["rpn.scores"], dev), T(g["rpn.regs"], dev), T(g["rpn.labels"], dev),
+                                      T(g["rpn.reg_labels"], dev), bad)
+    assert torch.isnan(loss).all()
+
+
 def test_determinism(dev):
     """Same input twice -> identical bits (no atomics-order dependence anywhere on the path)."""
     from objectdetection_amd import ops

@@ -87,6 +87,22 @@ def test_box_regression_backward(oracle, K):
     assert (g[f"k{K}.grad_regs"][1, 3::4] != 0).all() and (grad_regs[1, 3::4] != 0).all()      # == clamp: passes
 
 
+def test_sampled_losses(oracle):
+    """loss tails of both training branches and their gradients (losses.npz)."""
+    g = load_golden("losses.npz")
+    loss, gs, gr = oracle.rpn_sampled_loss(g["rpn.scores"], g["rpn.regs"], g["rpn.labels"], g["rpn.reg_labels"],
+                                           g["rpn.index"])
+    np.testing.assert_allclose(loss, [g["rpn.cls_loss"], g["rpn.reg_loss"]], rtol=1e-5)
+    up = g["rpn.upstream"]
+    np.testing.assert_allclose(gs * up[0], g["rpn.grad_scores"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(gr * up[1], g["rpn.grad_regs"], rtol=1e-5, atol=1e-8)
+    loss, gl, gp = oracle.roi_loss(g["roi.logits"], g["roi.pred"], g["roi.cls_label"], g["roi.reg_label"])
+    np.testing.assert_allclose(loss, [g["roi.cls_loss"], g["roi.reg_loss"]], rtol=1e-5)
+    up = g["roi.upstream"]
+    np.testing.assert_allclose(gl * up[0], g["roi.grad_logits"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(gp * up[1], g["roi.grad_pred"], rtol=1e-5, atol=1e-8)
+
+
 def test_clip_and_small_filter(oracle):
     g = load_golden("decode.npz")
     h, w = (int(v) for v in g["clip.image_size"])
