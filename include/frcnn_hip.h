@@ -196,6 +196,14 @@ int frcnn_roi_loss_f32(const float *logits, const float *pred, const float *cls_
                        const float *reg_label, int N, int Kc, float beta, float *loss_out,
                        float *grad_logits, float *grad_pred, void *stream);
 
+/* ---- batch assembly in front of the path ----------------------------------
+ * generalized_transform.py:58-64 + utils.py:362-369 for ONE image: bilinear resize (torch
+ * F.interpolate, align_corners=False, scale = in/out as with recompute_scale_factor=True) of
+ * src (C,in_h,in_w) to (out_h,out_w), written into the top-left corner of dst (C,canvas_h,canvas_w),
+ * zeros elsewhere.  out == in gives the plain zero-padded copy of utils.batched_images. */
+int frcnn_resize_pad_f32(const float *src, int C, int in_h, int in_w, int out_h, int out_w,
+                         float *dst, int canvas_h, int canvas_w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

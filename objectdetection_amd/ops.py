@@ -164,6 +164,22 @@ class BoxRegression(torch.autograd.Function):
         return (grad_box if need_box else None), (grad_regs if ctx.needs_input_grad[1] else None)
 
 
+def resize_pad_into(image, out_h, out_w, canvas):
+    """Bilinear resize of image (C,h,w) to (out_h,out_w) into the top-left of canvas (C,H,W), zeros elsewhere
+    (generalized_transform.py:58-64 + utils.py:362-369 fused).  canvas is written in full."""
+    _need_gpu(image, canvas)
+    image = _f32c(image)
+    if image.dim() != 3 or canvas.dim() != 3 or canvas.shape[0] != image.shape[0] or not canvas.is_contiguous() \
+            or canvas.dtype != torch.float32:
+        raise ValueError("resize_pad_into expects image (C,h,w) and a contiguous fp32 canvas (C,H,W)")
+    C, h, w = image.shape
+    with torch.cuda.device(image.device):
+        rc = _lib.load().frcnn_resize_pad_f32(_ptr(image), C, h, w, int(out_h), int(out_w), _ptr(canvas),
+                                              canvas.shape[1], canvas.shape[2], _stream())
+    _lib.check(rc, "resize_pad")
+    return canvas
+
+
 SMOOTH_L1_BETA = 1.0 / 9  # utils.py:315
 
 

@@ -17,7 +17,13 @@ from . import ops
 
 # Thin aliases in BASELINE.json's vocabulary (decision 1)
 __all__ = ["box_iou", "box_deviation", "box_regression", "remove_small_box", "box_clip", "tagging_box",
-           "get_sampling_factor", "smooth_l1_loss", "loc2bbox", "bbox2loc", "bbox_iou"]
+           "get_sampling_factor", "smooth_l1_loss", "batched_images", "loc2bbox", "bbox2loc", "bbox_iou"]
+
+
+def batched_images(images, divide_size):
+    """utils.py:339-372 -- zero-pad a list of (C,h,w) images into one (B,C,H,W) batch (on the device)."""
+    from .generalized_transform import batched_images as impl
+    return impl(images, divide_size)
 
 
 def box_iou(box_1, box_2):

@@ -258,6 +258,36 @@ void orc_box_regression_backward(const float *box, const float *regs, const floa
     }
 }
 
+/* generalized_transform.py:58-64 (torch upsample_bilinear2d, align_corners=False, scale = in/out)
+ * + utils.py:362-369 (copy into a zero canvas) for one image. */
+void orc_resize_pad(const float *src, int C, int in_h, int in_w, int out_h, int out_w, float *dst,
+                    int canvas_h, int canvas_w)
+{
+    const float scale_h = (float)in_h / (float)out_h, scale_w = (float)in_w / (float)out_w;
+    memset(dst, 0, sizeof(float) * (size_t)C * canvas_h * canvas_w);
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < out_h; ++y) {
+            float sy = scale_h * ((float)y + 0.5f) - 0.5f;
+            sy = sy < 0.0f ? 0.0f : sy;
+            int y0 = (int)sy;
+            y0 = y0 > in_h - 1 ? in_h - 1 : y0;
+            int y1 = y0 < in_h - 1 ? y0 + 1 : y0;
+            float ly = sy - (float)y0, hy = 1.0f - ly;
+            for (int x = 0; x < out_w; ++x) {
+                float sx = scale_w * ((float)x + 0.5f) - 0.5f;
+                sx = sx < 0.0f ? 0.0f : sx;
+                int x0 = (int)sx;
+                x0 = x0 > in_w - 1 ? in_w - 1 : x0;
+                int x1 = x0 < in_w - 1 ? x0 + 1 : x0;
+                float lx = sx - (float)x0, hx = 1.0f - lx;
+                const float *p = src + (size_t)c * in_h * in_w;
+                dst[((size_t)c * canvas_h + y) * canvas_w + x] =
+                    hy * (hx * p[y0 * in_w + x0] + lx * p[y0 * in_w + x1]) +
+                    ly * (hx * p[y1 * in_w + x0] + lx * p[y1 * in_w + x1]);
+            }
+        }
+}
+
 /* utils.py:331-333 element: x = |d|; x < beta ? 0.5 x^2 / beta : x - 0.5 beta; *g = d/d y_hat. */
 static float orc_sl1(float y_hat, float y, float beta, float *g)
 {

@@ -172,6 +172,59 @@ def box_regression_backward(box, regs, grad_out):
     return grad_regs, grad_box
 
 
+def transform_sizes(shapes, min_size, max_size):
+    """Host logic of generalized_transform.py:46-56 + utils.py:351-360, bugs included.
+    shapes: [(C,h,w)] -> ([(out_h,out_w)], canvas_h, canvas_w).  The `if` at :54 is always true up to
+    rounding, so the scale is max_size / max(h,w); the `elif` at utils.py:356 skips the width of any
+    image that raised the height."""
+    import math
+    outs = []
+    for _, h, w in shapes:
+        mn, mx = float(min(h, w)), float(max(h, w))
+        scale = min_size / mn
+        if mn * scale >= min_size:
+            scale = max_size / mx
+        outs.append((int(math.floor(float(h) * scale)), int(math.floor(float(w) * scale))))
+    return (outs,) + canvas_size(outs, 32)
+
+
+def canvas_size(sizes, divide_size):
+    """utils.py:351-360: max height / width scan with its `elif`, rounded up to divide_size."""
+    import math
+    max_h = max_w = 0
+    for h, w in sizes:
+        if h > max_h:
+            max_h = h
+        elif w > max_w:
+            max_w = w
+    return math.ceil(max_h / divide_size) * divide_size, math.ceil(max_w / divide_size) * divide_size
+
+
+def resize_pad(image, out_h, out_w, canvas_h, canvas_w):
+    image = _f32(image)
+    C, h, w = image.shape
+    out = np.empty((C, canvas_h, canvas_w), np.float32)
+    lib().orc_resize_pad(_fp(image), ctypes.c_int(C), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(out_h),
+                         ctypes.c_int(out_w), _fp(out), ctypes.c_int(canvas_h), ctypes.c_int(canvas_w))
+    return out
+
+
+def generalized_transform(images, boxes, min_size, max_size):
+    """GeneralizedTransform.forward -> (batch (B,C,H,W), [flattened rescaled boxes]); raises ValueError where
+    the reference's canvas is too small for an image (it raises a RuntimeError there)."""
+    outs, ch, cw = transform_sizes([im.shape for im in images], min_size, max_size)
+    batch, new_boxes = [], []
+    for im, box, (oh, ow) in zip(images, boxes, outs):
+        if oh > ch or ow > cw:
+            raise ValueError("image does not fit the canvas")
+        batch.append(resize_pad(im, oh, ow, ch, cw))
+        rh = np.float32(im.shape[1] / oh)      # generalized_transform.py:69-74: old / new (inverse, as written)
+        rw = np.float32(im.shape[2] / ow)
+        box = _f32(box)
+        new_boxes.append(np.concatenate([box[:, 0] * rw, box[:, 1] * rh, box[:, 2] * rw, box[:, 3] * rh]))
+    return np.stack(batch), new_boxes
+
+
 def rpn_sampled_loss(scores, regs, labels, reg_labels, index, beta=1.0 / 9):
     """rpn.py:122-137 -> (loss (2), grad_scores, grad_regs) with the inputs' shapes."""
     scores, regs, labels, reg_labels = _f32(scores), _f32(regs), _f32(labels), _f32(reg_labels)

@@ -16,6 +16,8 @@ reference's own functions produced for them:
                                            (torch autograd through it) -> decode_grad.npz
   code/FasterRCNN/utils.py                 smooth_l1_loss + torch BCE/CE on
                                            sampled rows, with gradients -> losses.npz
+  code/FasterRCNN/generalized_transform.py GeneralizedTransform.forward,
+  code/FasterRCNN/utils.py                 batched_images             -> transform.npz
   code/FasterRCNN/utils.py                 get_sampling_factor        -> sampling.npz
   RPN/rpn.py:55-83 call sequence replayed with the reference's utils
   functions and torch.topk (rpn.py itself cannot be imported: it needs
@@ -280,6 +282,47 @@ def gen_losses():
     save("losses.npz", **out)
 
 
+def gen_transform():
+    """batch assembly before the path -- GeneralizedTransform.forward
+    (generalized_transform.py:44-83: bilinear resize to max_size, GT rescale, pad to a multiple of 32 via
+    utils.batched_images, utils.py:339-372), bugs included (inverse box ratio, boxes flattened to 1-D by
+    torch.cat, the `elif` in the max-width scan)."""
+    from generalized_transform import GeneralizedTransform
+    g = torch.Generator().manual_seed(31337)
+    out = {}
+    cases = {"a": (80, 96, [(3, 37, 50), (3, 60, 41), (3, 33, 33)]),      # (min_size, max_size, image shapes)
+             "b": (64, 64, [(3, 64, 48), (3, 20, 64)]),                   # scale 1 on one side
+             "c": (100, 150, [(1, 11, 7), (1, 9, 12)]),                   # strong upsample, one channel
+             "d": (100, 150, [(1, 11, 7)])}                               # single image: the `elif` leaves width 0
+    for name, (mn, mx, shapes) in cases.items():
+        images = [torch.rand(*s, generator=g) for s in shapes]
+        targets = []
+        for s in shapes:
+            m = 3
+            xy = torch.rand(m, 2, generator=g) * torch.tensor([s[2] / 2.0, s[1] / 2.0])
+            wh = torch.rand(m, 2, generator=g) * torch.tensor([s[2] / 2.0, s[1] / 2.0]) + 1
+            targets.append({"box": torch.cat([xy, xy + wh], 1)})
+        for i, (im, t) in enumerate(zip(images, targets)):
+            out[f"{name}.image{i}"] = im.numpy().copy()
+            out[f"{name}.box{i}"] = t["box"].numpy().copy()
+        out[f"{name}.sizes"] = np.asarray([mn, mx, len(shapes)])
+        try:
+            batch, new_targets = GeneralizedTransform(mn, mx)(list(images), targets)
+        except RuntimeError:
+            out[f"{name}.raises"] = np.asarray([1])      # the reference itself fails on this input
+            continue
+        out[f"{name}.raises"] = np.asarray([0])
+        out[f"{name}.batch"] = batch.numpy()
+        for i, t in enumerate(new_targets):
+            out[f"{name}.new_box{i}"] = t["box"].numpy()
+    # batched_images alone (utils.py:339-372)
+    imgs = [torch.rand(3, 30, 45, generator=g), torch.rand(3, 50, 20, generator=g), torch.rand(3, 40, 70, generator=g)]
+    for i, im in enumerate(imgs):
+        out[f"pad.image{i}"] = im.numpy()
+    out["pad.batch"] = R.batched_images(list(imgs), 32).numpy()
+    save("transform.npz", **out)
+
+
 def gen_sampling():
     out = {}
     cases = [(256, 0.5, 40, 18000), (256, 0.5, 300, 18000), (128, 0.25, 10, 1500), (512, 0.25, 0, 60),
@@ -358,5 +401,6 @@ if __name__ == "__main__":
     gen_decode()
     gen_decode_grad()
     gen_losses()
+    gen_transform()
     gen_sampling()
     gen_rpn_stages()

@@ -618,6 +618,28 @@ def test_sampled_losses_golden(dev, oracle):
     assert torch.isnan(loss).all()
 
 
+def test_generalized_transform_golden(dev):
+    """GeneralizedTransform / batched_images against the reference's outputs."""
+    from objectdetection_amd.generalized_transform import GeneralizedTransform
+    from objectdetection_amd import utils as U
+    g = load_golden("transform.npz")
+    for name in "abcd":
+        mn, mx, n = (int(v) for v in g[f"{name}.sizes"])
+        images = [T(g[f"{name}.image{i}"], dev) for i in range(n)]
+        targets = [{"box": T(g[f"{name}.box{i}"], dev)} for i in range(n)]
+        if int(g[f"{name}.raises"][0]):
+            with pytest.raises(ValueError):
+                GeneralizedTransform(mn, mx)(images, targets)
+            continue
+        batch, new_targets = GeneralizedTransform(mn, mx)(images, targets)
+        assert batch.is_cuda and tuple(batch.shape) == g[f"{name}.batch"].shape
+        np.testing.assert_allclose(batch.cpu().numpy(), g[f"{name}.batch"], rtol=RTOL, atol=5e-6)
+        for i in range(n):
+            np.testing.assert_allclose(new_targets[i]["box"].cpu().numpy(), g[f"{name}.new_box{i}"], rtol=1e-6)
+    batch = U.batched_images([T(g[f"pad.image{i}"], dev) for i in range(3)], 32)
+    assert_bits_equal(batch.cpu().numpy(), g["pad.batch"])
+
+
 def test_determinism(dev):
     """Same input twice -> identical bits (no atomics-order dependence anywhere on the path)."""
     from objectdetection_amd import ops

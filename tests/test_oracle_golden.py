@@ -103,6 +103,29 @@ def test_sampled_losses(oracle):
     np.testing.assert_allclose(gp * up[1], g["roi.grad_pred"], rtol=1e-5, atol=1e-8)
 
 
+def test_generalized_transform(oracle):
+    """resize + GT rescale + pad-to-32, quirks included (transform.npz)."""
+    g = load_golden("transform.npz")
+    for name in "abcd":
+        mn, mx, n = (int(v) for v in g[f"{name}.sizes"])
+        images = [g[f"{name}.image{i}"] for i in range(n)]
+        boxes = [g[f"{name}.box{i}"] for i in range(n)]
+        if int(g[f"{name}.raises"][0]):
+            with pytest.raises(ValueError):
+                oracle.generalized_transform(images, boxes, mn, mx)
+            continue
+        batch, new_boxes = oracle.generalized_transform(images, boxes, mn, mx)
+        assert batch.shape == g[f"{name}.batch"].shape
+        np.testing.assert_allclose(batch, g[f"{name}.batch"], rtol=1e-5, atol=5e-6)  # torch groups the 4 products differently
+        for i in range(n):
+            np.testing.assert_allclose(new_boxes[i], g[f"{name}.new_box{i}"], rtol=1e-6)
+    ch, cw = oracle.canvas_size([(30, 45), (50, 20), (40, 70)], 32)
+    assert (3, 3, ch, cw) == g["pad.batch"].shape
+    for i in range(3):
+        im = g[f"pad.image{i}"]
+        assert_bits_equal(oracle.resize_pad(im, im.shape[1], im.shape[2], ch, cw), g["pad.batch"][i])
+
+
 def test_clip_and_small_filter(oracle):
     g = load_golden("decode.npz")
     h, w = (int(v) for v in g["clip.image_size"])
