@@ -305,6 +305,7 @@ def main():
             ser, _, _ = run_workload(path, dev, None, 0, 1, B, args.workload, max(5, args.steps // 2), 2, pipelined=False)
             extras["serial"] = {k: ser[k] for k in ("value", "ms_per_step", "stage_ms")}
         extras.update(nms_microbench(path, dev))
+        extras.update(next_rows_microbench(dev))
 
     if rank == 0:
         desc = {"realistic": "proposal-realistic deltas (NMS keeps 2000/img)",
@@ -340,6 +341,60 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def next_rows_microbench(dev):
+    """SURVEY 8f rows 2-4 (the callers either side of the path): time and algorithmic bytes of each launch."""
+    from objectdetection_amd import ops
+    from objectdetection_amd.generalized_transform import GeneralizedTransform
+    g = torch.Generator().manual_seed(99)
+    B = 16
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    res = {}
+    # row 3: batch assembly, 16 images 3x600x1000 -> max side 1000 (scale 1) -> (16,3,608,1024)
+    images = [torch.rand(3, IMG_H, IMG_W, generator=g).to(dev) for _ in range(B)]
+    gt = GeneralizedTransform(600, 1000)
+    ms = timed(lambda: gt(list(images), [None] * B))
+    nbytes = B * 3 * (IMG_H * IMG_W + 608 * 1024) * 4
+    res["batch_assembly"] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / ms / 1e6,
+                             "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "launches": B}
+    # row 2: RPN loss tail, 256 sampled anchors per image out of A; forward + gradients in one launch (+2 memsets)
+    scores = torch.randn(B, A, generator=g).to(dev)
+    regs = torch.randn(B, A, 4, generator=g).to(dev)
+    labels = (torch.rand(B, A, generator=g) < 0.5).float().to(dev)
+    reg_labels = torch.randn(B, A, 4, generator=g).to(dev)
+    index = torch.cat([torch.randperm(A, generator=g)[:256] + b * A for b in range(B)]).to(dev)
+    ms = timed(lambda: ops.rpn_sampled_loss(scores, regs, labels, reg_labels, index))
+    res["rpn_sampled_loss_fwd_bwd"] = {"ms": ms, "samples": int(index.numel()),
+                                       "algorithmic_bytes": int(index.numel()) * (8 + 40 + 20) + B * A * 20}
+    # row 2: RoI loss tail, 128 sampled proposals per image, 21 classes
+    N, Kc = 128 * B, 21
+    logits = torch.randn(N, Kc, generator=g).to(dev)
+    pred = torch.randn(N, Kc * 4, generator=g).to(dev)
+    cls_label = torch.randint(0, Kc, (N,), generator=g).float().to(dev)
+    reg_label = torch.randn(N, 4, generator=g).to(dev)
+    ms = timed(lambda: ops.roi_loss(logits, pred, cls_label, reg_label))
+    res["roi_loss_fwd_bwd"] = {"ms": ms, "rows": N, "algorithmic_bytes": N * (Kc * 20 * 2 + 20)}
+    # row 4: decode backward on the batch's 16 x 12,000 candidates
+    n = B * PRE_NMS
+    box = torch.rand(n, 4, generator=g).to(dev) * 500
+    box[:, 2:] += box[:, :2] + 1
+    dl = (torch.randn(n, 4, generator=g) * 0.2).to(dev)
+    up = torch.randn(n, 4, generator=g).to(dev)
+    ms = timed(lambda: ops.box_regression_backward(box, dl, up))
+    res["decode_backward"] = {"ms": ms, "rows": n, "algorithmic_bytes": n * 80, "GBps": n * 80 / ms / 1e6}
+    return {"next_rows": res}
 
 
 def nms_microbench(path, dev):
