@@ -239,6 +239,14 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
     # ... and of the rest of the path: scores read, top-k out, gathers, boxes, keeps
     rest_bytes = B * (A * 4 + PRE_NMS * 8 + PRE_NMS * 32 + PRE_NMS * 20 + PRE_NMS * 20 + POST_NMS * 24)
     ra_ms = stage_ms["roi_align"]
+    traffic = None  # HBM bytes per launch from a separate rocprofv3 --pmc pass, valid for this exact launch shape
+    try:
+        with open(os.path.join(ROOT, "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("rois") == n_rois and B == 16:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     res = dict(workload=workload, value=world * B * steps / elapsed, ms_per_step=ms_per_step, stage_ms=stage_ms,
                roi_queue_wait_ms=queue_wait,
                proposals_per_image_mean=float(np.mean(counts)), rois_per_step=n_rois,
@@ -246,7 +254,9 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
                path_hbm_frac=(roi_bytes + rest_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                roofline=dict(bound="hbm", kernel="roi_align_plane_kernel", achieved=roi_bytes / (ra_ms * 1e-3) / 1e9,
                              peak=HBM_PEAK_GBPS, unit="GB/s", frac=roi_bytes / (ra_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             traffic=None, algorithmic_bytes_per_launch=roi_bytes, launch_ms=ra_ms,
+                             traffic=traffic, traffic_source="pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE, "
+                             "separate passes; profiles/r01_step2_roi_align_pmc.csv)" if traffic else None,
+                             algorithmic_bytes_per_launch=roi_bytes, launch_ms=ra_ms,
                              dominant_stage=max(stage_ms, key=stage_ms.get)))
     return res, props, n_keep
 
