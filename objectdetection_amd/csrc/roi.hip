@@ -323,7 +323,7 @@ __device__ __forceinline__ AxisTaps axis_taps3(const AxisSample &s0, const AxisS
     const int a = s0.lo;
     t.idx[0] = a;
     t.idx[1] = min(a + 1, n - 1);
-    t.idx[2] = min(a + 2, n - 1);
+    t.idx[2] = same ? a : min(a + 2, n - 1); // weight 0 when `same`: stay on a cell that is read anyway
     t.idx[3] = 0;
     // a clamped sample (lo == n-1) has whi == 0, so treating its hi tap as cell lo+1 is exact
     t.w[0] = (s0.wlo + (same ? s1.wlo : 0.0f)) * k;
@@ -530,13 +530,195 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
     }
 }
 
+// ---- planes too large for LDS (FPN P3 100x168, P2 200x336): windows of the plane -----------------
+// A RoI that the level mapper sends to a fine level is small in feature pixels, so the plane kernel's
+// scheme still works on a WINDOW of the plane: RAW_WIN x RAW_WIN pixels x 16 channels in LDS, windows
+// every RAW_STEP pixels.  A RoI belongs to the window that holds its first tap, and fits when its last
+// tap is inside too -- always the case when it spans at most RAW_WIN - RAW_STEP + 1 = 33 cells per
+// axis; the rare larger ones are left to the direct kernel, which is then launched with the same test
+// inverted.  Workgroup = (16-channel chunk, window, image); a window no RoI of the image falls into
+// costs one pass over the boxes and no staging.
+#define RAW_WIN 48
+#define RAW_STEP 16
+
+struct RoiWindow {
+    int win;   // iy * nwx + ix
+    bool fits; // every tap of the RoI lies inside that window
+};
+
+__device__ __forceinline__ float4 roi_record(float4 box, float scale)
+{
+    float start_w = box.x * scale, start_h = box.y * scale;
+    float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
+    roi_w = roi_w > 1.0f ? roi_w : 1.0f;
+    roi_h = roi_h > 1.0f ? roi_h : 1.0f;
+    return make_float4(start_w, start_h, roi_w / 7.0f, roi_h / 7.0f);
+}
+
+// Same expressions as the item loops use for bin 0 / sample 0 and bin 6 / sample 1: sample
+// coordinates grow with (bin, sample), so every tap lies between the first sample's low cell and the
+// last sample's high cell (samples outside the map have zero weight and are relocated by the caller).
+__device__ __forceinline__ RoiWindow roi_window(float4 rec, int H, int W, int nwy, int nwx)
+{
+    const AxisSample yf = axis_sample(rec.y + 0.0f * rec.w + (0.0f + 0.5f) * rec.w / 2.0f, H);
+    const AxisSample yl = axis_sample(rec.y + 6.0f * rec.w + (1.0f + 0.5f) * rec.w / 2.0f, H);
+    const AxisSample xf = axis_sample(rec.x + 0.0f * rec.z + (0.0f + 0.5f) * rec.z / 2.0f, W);
+    const AxisSample xl = axis_sample(rec.x + 6.0f * rec.z + (1.0f + 0.5f) * rec.z / 2.0f, W);
+    const int y_lo = yf.ok ? yf.lo : 0, y_hi = yl.ok ? yl.hi : H - 1;
+    const int x_lo = xf.ok ? xf.lo : 0, x_hi = xl.ok ? xl.hi : W - 1;
+    const int iy = min(y_lo / RAW_STEP, nwy - 1), ix = min(x_lo / RAW_STEP, nwx - 1);
+    RoiWindow r;
+    r.win = iy * nwx + ix;
+    r.fits = y_hi < iy * RAW_STEP + RAW_WIN && x_hi < ix * RAW_STEP + RAW_WIN;
+    return r;
+}
+
+// taps of one axis relative to the window origin; zero-weight cells are pulled inside the window
+__device__ __forceinline__ void taps_to_window(AxisTaps &t, int n_taps, int origin)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < n_taps) t.idx[i] = min(max(t.idx[i] - origin, 0), RAW_WIN - 1);
+}
+
+template <int GT>
+__global__ void __launch_bounds__(RAP_THREADS)
+roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
+                        const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
+                        float scale, int level, int n_levels, int k_min, int k_max, int nwy, int nwx,
+                        float *__restrict__ out, int32_t *__restrict__ total_out)
+{
+    extern __shared__ float4 s_plane[];
+    __shared__ float4 s_rec[RAP_SEG];
+    __shared__ int s_idx[RAP_SEG];
+    __shared__ int s_off, s_cnt, s_n;
+    const int b = blockIdx.z;
+    const int B = gridDim.z;
+    const int c0 = blockIdx.x * 16;
+    const int nc = min(16, C - c0);
+    const int G = GT ? GT : (nc + 3) >> 2;
+    const int HW = H * W;
+    const int wid = blockIdx.y;
+    const int wy0 = (wid / nwx) * RAW_STEP, wx0 = (wid % nwx) * RAW_STEP;
+    if (threadIdx.x == 0) {
+        int off = 0, tot = 0;
+        for (int i = 0; i < B; ++i) {
+            int c = count ? count[i] : P;
+            c = c < 0 ? 0 : (c > P ? P : c);
+            if (i < b) off += c;
+            if (i == b) s_cnt = c;
+            tot += c;
+        }
+        s_off = off;
+        if (total_out && blockIdx.x == 0 && blockIdx.y == 0 && b == 0) *total_out = tot;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    const float4 *pb = props + (long long)b * P;
+    // does any RoI of the image belong here?  (decides whether the window is staged at all)
+    int mine = 0;
+    for (int i = threadIdx.x; i < cnt; i += RAP_THREADS) {
+        const float4 box = pb[i];
+        int lv = 0;
+        if (n_levels > 1) lv = map_level(box, k_min, k_max);
+        const RoiWindow rw = roi_window(roi_record(box, scale), H, W, nwy, nwx);
+        mine |= (lv == level && rw.fits && rw.win == wid) ? 1 : 0;
+    }
+    if (!__syncthreads_or(mine)) return;
+    // stage the window: rows wy0.. and columns wx0.. that exist in the plane
+    const int wh = min(RAW_WIN, H - wy0), ww = min(RAW_WIN, W - wx0);
+    const float *fb = feat + ((long long)b * C + c0) * HW;
+    const int per_g = wh * ww;
+    for (int t0 = threadIdx.x; t0 < G * per_g; t0 += 4 * RAP_THREADS) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * RAP_THREADS;
+            v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (t < G * per_g) {
+                const int g = t / per_g;
+                const int p = t - g * per_g;
+                const int ly = p / ww, lx = p - ly * ww;
+                const float *f = fb + (long long)(4 * g) * HW + (long long)(wy0 + ly) * W + wx0 + lx;
+                v[u].x = f[0];
+                if (4 * g + 1 < nc) v[u].y = f[HW];
+                if (4 * g + 2 < nc) v[u].z = f[2 * HW];
+                if (4 * g + 3 < nc) v[u].w = f[3 * HW];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * RAP_THREADS;
+            if (t < G * per_g) {
+                const int g = t / per_g;
+                const int p = t - g * per_g;
+                const int ly = p / ww, lx = p - ly * ww;
+                s_plane[(ly * G + g) * RAW_WIN + (lx ^ rap_swz(ly))] = v[u];
+            }
+        }
+    }
+    const int row_stride = G * RAW_WIN;
+    float *ob = out + ((long long)s_off * C + c0) * 49;
+    const int bin = threadIdx.x & 63;
+    const int ph = bin / 7, pw = bin - ph * 7;
+    for (int seg = 0; seg < cnt; seg += RAP_SEG) {
+        const int nseg = min(RAP_SEG, cnt - seg);
+        __syncthreads(); // staging done / readers of the previous segment's list are done
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nseg; i += RAP_THREADS) {
+            const float4 box = pb[seg + i];
+            int lv = 0;
+            if (n_levels > 1) lv = map_level(box, k_min, k_max);
+            const float4 rec = roi_record(box, scale);
+            const RoiWindow rw = roi_window(rec, H, W, nwy, nwx);
+            if (lv == level && rw.fits && rw.win == wid) {
+                const int pos = atomicAdd(&s_n, 1);
+                s_rec[pos] = rec;
+                s_idx[pos] = seg + i;
+            }
+        }
+        __syncthreads();
+        const int n_list = s_n;
+        // one whole RoI per wave iteration, lane = bin (see roi_align_plane_kernel)
+        for (int e = (int)(threadIdx.x >> 6); e < (bin < 49 ? n_list : 0); e += RAP_THREADS / 64) {
+            const float4 rec = s_rec[e];
+            float *o = ob + (long long)s_idx[e] * C * 49 + bin;
+            const float start_w = rec.x, start_h = rec.y, bin_w = rec.z, bin_h = rec.w;
+            AxisSample ys[2], xs[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
+                xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
+            }
+            const bool y3 = __all(axis_mergeable(ys[0], ys[1]));
+            const bool x3 = __all(axis_mergeable(xs[0], xs[1]));
+            AxisTaps ty = y3 ? axis_taps3(ys[0], ys[1], 0.25f, H) : axis_taps4(ys[0], ys[1], 0.25f);
+            AxisTaps tx = x3 ? axis_taps3(xs[0], xs[1], 1.0f, W) : axis_taps4(xs[0], xs[1], 1.0f);
+            taps_to_window(ty, y3 ? 3 : 4, wy0);
+            taps_to_window(tx, x3 ? 3 : 4, wx0);
+            if (y3) {
+                if (x3)
+                    rap_item<3, 3, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+                else
+                    rap_item<3, 4, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+            } else {
+                if (x3)
+                    rap_item<4, 3, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+                else
+                    rap_item<4, 4, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+            }
+        }
+    }
+}
+
 // Generic batched fallback (any pooled size / sampling ratio / plane size): block = (RoI split,
 // 32-channel chunk, image); per RoI the sample table is rebuilt in LDS, taps come through L1.
 __global__ void __launch_bounds__(256)
 roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, int W,
                                 const float4 *__restrict__ props, const int32_t *__restrict__ count,
                                 int P, int pooled_h, int pooled_w, float scale, int sampling_ratio,
-                                int level, int n_levels, int k_min, int k_max,
+                                int level, int n_levels, int k_min, int k_max, int nwy, int nwx,
                                 float *__restrict__ out, int32_t *__restrict__ total_out)
 {
     __shared__ Sample s_samp[RA_MAX_SAMPLES];
@@ -573,6 +755,8 @@ roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, in
                 for (int t = threadIdx.x; t < nc * bins; t += blockDim.x) ob[t] = 0.0f;
             if (lv != level) continue;
         }
+        // behind the window kernel (nwy > 0): only the RoIs that fit no window are left to do
+        if (nwy > 0 && roi_window(roi_record(box, scale), H, W, nwy, nwx).fits) continue;
         float start_w = box.x * scale, start_h = box.y * scale;
         float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
         roi_w = roi_w > 1.0f ? roi_w : 1.0f;
@@ -665,11 +849,44 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         FRCNN_CHECK_LAUNCH("roi_align_plane");
         return FRCNN_OK;
     }
+    int nwy = 0, nwx = 0;
+    if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && (long long)P * 49 < (1ll << 30) &&
+        (long long)H * W < (1ll << 28)) {
+        // plane too large for LDS: windows of it (fine pyramid levels, where RoIs are small)
+        nwy = H <= RAW_WIN ? 1 : (H - RAW_WIN + RAW_STEP - 1) / RAW_STEP + 1;
+        nwx = W <= RAW_WIN ? 1 : (W - RAW_WIN + RAW_STEP - 1) / RAW_STEP + 1;
+        if ((long long)nwy * nwx > 65535) {
+            nwy = nwx = 0;
+        } else {
+            const int chunks16 = (C + 15) / 16;
+            const size_t lds = (size_t)RAW_WIN * RAW_WIN * 64;
+            const bool full = C % 16 == 0;
+            static bool configured4 = false, configured0 = false;
+            bool &configured = full ? configured4 : configured0;
+            if (!configured) {
+                hipError_t e = hipFuncSetAttribute(
+                    full ? (const void *)roi_align_window_kernel<4> : (const void *)roi_align_window_kernel<0>,
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
+                              hipGetErrorString(e));
+                configured = true;
+            }
+            if (full)
+                hipLaunchKernelGGL((roi_align_window_kernel<4>), dim3(chunks16, nwy * nwx, B), dim3(RAP_THREADS), lds,
+                                   (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P,
+                                   spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, out, total_out);
+            else
+                hipLaunchKernelGGL((roi_align_window_kernel<0>), dim3(chunks16, nwy * nwx, B), dim3(RAP_THREADS), lds,
+                                   (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P,
+                                   spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, out, total_out);
+            FRCNN_CHECK_LAUNCH("roi_align_window");
+        }
+    }
     int chunks = (C + RA_CHUNK - 1) / RA_CHUNK;
     int splits = P < 128 ? P : 128;
     hipLaunchKernelGGL(roi_align_batched_direct_kernel, dim3(splits, chunks, B), dim3(256), 0,
                        (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, pooled_h,
-                       pooled_w, spatial_scale, sampling_ratio, level, n_levels, k_min, k_max, out,
+                       pooled_w, spatial_scale, sampling_ratio, level, n_levels, k_min, k_max, nwy, nwx, out,
                        total_out);
     FRCNN_CHECK_LAUNCH("roi_align_batched_direct");
     return FRCNN_OK;

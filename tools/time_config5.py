@@ -27,7 +27,11 @@ off = 0
 for h, w in fsz:
     n = h * w * NA
     cx, cy = torch.rand(B, n, generator=g) * Wimg, torch.rand(B, n, generator=g) * Himg
-    wt, ht = 16 * 2 ** (torch.rand(B, n, generator=g) * 5.5), 16 * 2 ** (torch.rand(B, n, generator=g) * 5.5)
+    # object size 16 .. 724 px, aspect ratio 1:3 .. 3:1 (independent w and h would make a third of the
+    # fine-level RoIs 5:1 and longer, which no detector proposes)
+    size = 16 * 2 ** (torch.rand(B, n, generator=g) * 5.5)
+    ratio = 2 ** ((torch.rand(B, n, generator=g) * 2 - 1) * 1.585)
+    wt, ht = size * ratio.sqrt(), size / ratio.sqrt()
     w_, h_ = wa[off:off + n], ha[off:off + n]
     d = torch.stack([(cx - w_ / 2) / w_, (cy - h_ / 2) / h_, torch.log(wt / w_), torch.log(ht / h_)], 2)
     reg.append(d.reshape(B, h, w, 4 * NA).permute(0, 3, 1, 2).contiguous().to(dev)); off += n
