@@ -475,11 +475,152 @@ topk_reg_kernel(const float *__restrict__ scores, int n, int k, float *__restric
     }
 }
 
+// ---- full-sort variant (k is a large part of n) ---------------------------------------------------
+// When most of the image is kept (the RPN keeps 12,000 of 20,646 anchors) selecting first saves
+// little: 4 select passes over n, a compaction and 4 sort passes over k cost more than SORTING all
+// n keys with wider digits.  This kernel is a stable LSD radix sort of the whole image in 3 passes
+// of 11-bit digits (descending key; the input is in index order, so ties come out by ascending
+// index) whose last pass scatters only the first k positions, straight into the outputs.
+// Per pass a wave owns a contiguous segment, held in registers (KR rounds of 64): rank inside the
+// wave by 11-ballot matching, wave-private digit counters in LDS (16 x 2048 words = 128 KB),
+// one cross-wave scan, fire-and-forget scatter to the ping-pong buffers (L2-resident).
+#define TOPK_SORT_BITS 11
+#define TOPK_SORT_BINS (1 << TOPK_SORT_BITS)
+
+__device__ __forceinline__ unsigned long long wave_match11(unsigned digit, bool active)
+{
+    unsigned long long peers = __ballot(active);
+#pragma unroll
+    for (int bit = 0; bit < TOPK_SORT_BITS; ++bit) {
+        bool one = (digit >> bit) & 1u;
+        unsigned long long bm = __ballot(one);
+        peers &= one ? bm : ~bm;
+    }
+    return peers;
+}
+
+template <int KR>
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ val_out,
+                 int32_t *__restrict__ idx_out, uint32_t *__restrict__ ws)
+{
+    __shared__ unsigned s_cnt[TOPK_WAVES][TOPK_SORT_BINS];
+    __shared__ unsigned s_base[TOPK_SORT_BINS];
+    __shared__ unsigned s_wsum[2][TOPK_WAVES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float *sc = scores + (long long)b * n;
+    uint32_t *keyA = ws + (long long)b * 4 * n;
+    uint32_t *idxA = keyA + n;
+    uint32_t *keyB = idxA + n;
+    uint32_t *idxB = keyB + n;
+    const int seg = ((n + TOPK_WAVES - 1) / TOPK_WAVES + 63) / 64 * 64;
+    const int seg_lo = min(wave * seg, n);
+    const int seg_hi = min(seg_lo + seg, n);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t *kin = keyA, *iin = idxA, *kout = keyB, *iout = idxB;
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass * TOPK_SORT_BITS;
+        // ireg: index in bits 0..14 (n < 2^15), then the element's rank among its digit peers of the
+        // wave (bits 16..21) and their number (bits 24..30) once known
+        unsigned kreg[KR], ireg[KR];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            const int e = seg_lo + r * 64 + lane;
+            const bool act = e < seg_hi;
+            if (pass == 0) {
+                kreg[r] = act ? frcnn_score_key(sc[e]) : 0u;
+                ireg[r] = (unsigned)e;
+            } else {
+                kreg[r] = act ? kin[e] : 0u;
+                ireg[r] = act ? iin[e] : 0u;
+            }
+        }
+        for (int t = tid; t < TOPK_WAVES * TOPK_SORT_BINS; t += TOPK_THREADS) (&s_cnt[0][0])[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            if (seg_lo + r * 64 < seg_hi) { // wave-uniform
+                const bool act = seg_lo + r * 64 + lane < seg_hi;
+                const unsigned dg = (TOPK_SORT_BINS - 1) - ((kreg[r] >> shift) & (TOPK_SORT_BINS - 1));
+                const unsigned long long peers = wave_match11(dg, act);
+                const unsigned rank = (unsigned)__popcll(peers & lt);
+                const unsigned cnt = (unsigned)__popcll(peers);
+                ireg[r] |= (rank << 16) | (cnt << 24);
+                if (act && rank == 0) atomicAdd(&s_cnt[wave][dg], cnt);
+            }
+        }
+        __syncthreads();
+        // per digit: exclusive scan over the waves; thread t owns digits 2t and 2t+1 (adjacent, so the
+        // scan over digits below is a scan over threads)
+        unsigned tot0 = 0, tot1 = 0;
+#pragma unroll
+        for (int w = 0; w < TOPK_WAVES; ++w) {
+            const unsigned c0 = s_cnt[w][2 * tid], c1 = s_cnt[w][2 * tid + 1];
+            s_cnt[w][2 * tid] = tot0;
+            s_cnt[w][2 * tid + 1] = tot1;
+            tot0 += c0;
+            tot1 += c1;
+        }
+        {
+            const unsigned mine = tot0 + tot1;
+            unsigned incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) s_wsum[pass & 1][wave] = incl;
+            __syncthreads();
+            unsigned wbase = 0;
+#pragma unroll
+            for (int w = 0; w < TOPK_WAVES; ++w) wbase += w < wave ? s_wsum[pass & 1][w] : 0u;
+            const unsigned excl = wbase + incl - mine;
+            s_base[2 * tid] = excl;
+            s_base[2 * tid + 1] = excl + tot0;
+        }
+        __syncthreads();
+        volatile unsigned *wcnt = s_cnt[wave];
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+            if (seg_lo + r * 64 < seg_hi) {
+                const bool act = seg_lo + r * 64 + lane < seg_hi;
+                if (act) {
+                    const unsigned dg = (TOPK_SORT_BINS - 1) - ((kreg[r] >> shift) & (TOPK_SORT_BINS - 1));
+                    const unsigned rank = (ireg[r] >> 16) & 63u, cnt = ireg[r] >> 24;
+                    const unsigned idx = ireg[r] & 0x7FFFu;
+                    const unsigned off = wcnt[dg];
+                    const unsigned pos = s_base[dg] + off + rank;
+                    if (pass == 2) {
+                        if (pos < (unsigned)k) {
+                            idx_out[(long long)b * k + pos] = (int32_t)idx;
+                            if (val_out) val_out[(long long)b * k + pos] = sc[idx];
+                        }
+                    } else {
+                        kout[pos] = kreg[r];
+                        iout[pos] = idx;
+                    }
+                    if (rank == 0) wcnt[dg] = off + cnt;
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *ti = iin; iin = iout; iout = ti;
+    }
+}
+
+#define TOPK_SORT_KR 21
+static bool topk_use_sort(int n, int k) { return n <= TOPK_SORT_KR * TOPK_THREADS && 2LL * k >= n && n > 8 * TOPK_THREADS; }
+
 extern "C" size_t frcnn_topk_workspace_bytes(int B, int n, int k)
 {
-    (void)n;
     if (B <= 0 || k <= 0) return 0;
-    return (size_t)B * 4 * (size_t)k * sizeof(uint32_t);
+    const size_t per = topk_use_sort(n, k) ? (size_t)n : (size_t)k;
+    return (size_t)B * 4 * per * sizeof(uint32_t);
 }
 
 extern "C" int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, float *val_out,
@@ -494,7 +635,10 @@ extern "C" int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, flo
                         frcnn_topk_workspace_bytes(B, n, k));
         return FRCNN_EWORKSPACE;
     }
-    if (n <= 8 * TOPK_THREADS && k <= 8 * TOPK_THREADS)
+    if (topk_use_sort(n, k))
+        hipLaunchKernelGGL((topk_sort_kernel<TOPK_SORT_KR>), dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream,
+                           scores, n, k, val_out, idx_out, (uint32_t *)workspace);
+    else if (n <= 8 * TOPK_THREADS && k <= 8 * TOPK_THREADS)
         hipLaunchKernelGGL((topk_reg_kernel<8, 8>), dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream,
                            scores, n, k, val_out, idx_out, (uint32_t *)workspace);
     else if (n <= 24 * TOPK_THREADS && k <= 12 * TOPK_THREADS)
