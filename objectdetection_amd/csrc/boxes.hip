@@ -251,7 +251,25 @@ extern "C" int frcnn_select_gt_f32(const float *value, int n, float thresh, int6
     return FRCNN_OK;
 }
 
-// Fused gather + decode + clip + small-box compaction: one 1024-thread block per image.
+// Fused gather + decode + clip + small-box compaction.  Workgroup = (tile of 1024 candidates, image).
+// The compaction is order-preserving over the whole image, so a tile needs the number of rows kept in
+// the tiles before it: it simply re-evaluates their keep flags (a decode is ~40 instructions; the loads
+// of all earlier tiles are independent and overlap) and reduces once, instead of the image's tiles
+// being walked one after the other by a single workgroup (12 dependent gather round trips and 24
+// barriers at k = 12,000).
+__device__ __forceinline__ bool decode_row(const float4 *__restrict__ anc, const float4 *__restrict__ del,
+                                           const int32_t *__restrict__ idx, int i, float image_h,
+                                           float image_w, float min_size, float4 *p_out)
+{
+    const int a = idx[i];
+    float4 p = decode_one(anc[a], del[a], (float)FRCNN_DW_CLAMP);
+    p = clip_box(p, image_h, image_w);
+    *p_out = p;
+    const float w = p.z - p.x;
+    const float h = p.w - p.y;
+    return (w > min_size) && (h > min_size);
+}
+
 __global__ void __launch_bounds__(1024)
 decode_clip_filter_kernel(const float4 *__restrict__ anchors, long long anchor_batch_stride4,
                           const float4 *__restrict__ deltas, const int32_t *__restrict__ top_idx,
@@ -261,7 +279,9 @@ decode_clip_filter_kernel(const float4 *__restrict__ anchors, long long anchor_b
                           int32_t *__restrict__ count_out)
 {
     __shared__ int wave_sums[16];
-    const int b = blockIdx.x;
+    __shared__ int s_prior[16];
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;
     const float4 *anc = anchors + (long long)b * anchor_batch_stride4;
     const float4 *del = deltas + (long long)b * A;
     const int32_t *idx = top_idx + (long long)b * k;
@@ -269,31 +289,47 @@ decode_clip_filter_kernel(const float4 *__restrict__ anchors, long long anchor_b
     float4 *bo = boxes_out + (long long)b * k;
     float *so = scores_out + (long long)b * k;
     int32_t *ro = src_out + (long long)b * k;
-    int base = 0;
-    for (int start = 0; start < k; start += 1024) {
-        int i = start + threadIdx.x;
-        bool keep = false;
-        float4 p = make_float4(0, 0, 0, 0);
-        float s = 0.0f;
-        if (i < k) {
-            int a = idx[i];
-            s = sc[i];
-            p = decode_one(anc[a], del[a], (float)FRCNN_DW_CLAMP);
-            p = clip_box(p, image_h, image_w);
-            float w = p.z - p.x;
-            float h = p.w - p.y;
-            keep = (w > min_size) && (h > min_size);
+    // rows kept in the earlier tiles (all of them are full tiles)
+    int prior = 0;
+    for (int u0 = 0; u0 < tile; u0 += 4) { // four tiles' gathers in flight at a time
+        int a[4];
+        float4 an[4], de[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a[v] = u0 + v < tile ? idx[(u0 + v) * 1024 + (int)threadIdx.x] : 0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            an[v] = anc[a[v]];
+            de[v] = del[a[v]];
         }
-        int tot;
-        int pos = base + frcnn_block_excl_count(keep, wave_sums, &tot);
-        if (keep) {
-            bo[pos] = p;
-            so[pos] = s;
-            ro[pos] = i;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float4 q = clip_box(decode_one(an[v], de[v], (float)FRCNN_DW_CLAMP), image_h, image_w);
+            const bool kept = (q.z - q.x > min_size) && (q.w - q.y > min_size);
+            prior += (u0 + v < tile && kept) ? 1 : 0;
         }
-        base += tot;
     }
-    if (threadIdx.x == 0) count_out[b] = base;
+    for (int o = 32; o > 0; o >>= 1) prior += __shfl_down(prior, o);
+    if ((threadIdx.x & 63) == 0) s_prior[threadIdx.x >> 6] = prior;
+    // own tile
+    const int i = tile * 1024 + threadIdx.x;
+    bool keep = false;
+    float4 p = make_float4(0, 0, 0, 0);
+    float s = 0.0f;
+    if (i < k) {
+        s = sc[i];
+        keep = decode_row(anc, del, idx, i, image_h, image_w, min_size, &p);
+    }
+    int tot;
+    int pos = frcnn_block_excl_count(keep, wave_sums, &tot); // (its barriers also publish s_prior)
+    int base = 0;
+    for (int w = 0; w < 16; ++w) base += s_prior[w];
+    pos += base;
+    if (keep) {
+        bo[pos] = p;
+        so[pos] = s;
+        ro[pos] = i;
+    }
+    if (threadIdx.x == 0 && tile == (int)gridDim.x - 1) count_out[b] = base + tot;
 }
 
 extern "C" int frcnn_decode_clip_filter_f32(const float *anchors, int64_t anchor_batch_stride,
@@ -308,7 +344,8 @@ extern "C" int frcnn_decode_clip_filter_f32(const float *anchors, int64_t anchor
                       count_out,
                   "decode_clip_filter: null pointer");
     FRCNN_REQUIRE(anchor_batch_stride % 4 == 0, "decode_clip_filter: anchor stride not a box multiple");
-    hipLaunchKernelGGL(decode_clip_filter_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream,
+    FRCNN_REQUIRE(B <= 65535, "decode_clip_filter: batch too large");
+    hipLaunchKernelGGL(decode_clip_filter_kernel, dim3((k + 1023) / 1024, B), dim3(1024), 0, (hipStream_t)stream,
                        (const float4 *)anchors, (long long)(anchor_batch_stride / 4),
                        (const float4 *)deltas, top_idx, top_score, A, k, image_h, image_w, min_size,
                        (float4 *)boxes_out, scores_out, src_out, count_out);
