@@ -202,7 +202,10 @@ def test_empty_inputs(dev):
 
 
 # --------------------------------------------------------------------------------- top-k (K2)
-@pytest.mark.parametrize("B,n,k", [(1, 100, 100), (2, 5000, 1000), (3, 20646, 12000), (1, 70000, 30000), (2, 777, 1)])
+@pytest.mark.parametrize("B,n,k", [(1, 100, 100), (2, 5000, 1000), (3, 20646, 12000), (1, 70000, 30000), (2, 777, 1),
+                                   # edges of the full-sort path (k >= n/2, 8192 < n <= 21504) and just outside it
+                                   (2, 21504, 21504), (1, 8193, 4097), (1, 21505, 12000), (1, 8192, 8192),
+                                   (2, 20646, 10322)])
 def test_topk_vs_oracle(dev, oracle, B, n, k):
     from objectdetection_amd import ops
     rng = np.random.default_rng(n + k)
@@ -229,6 +232,19 @@ def test_topk_ties_and_specials(dev, oracle):
         v, i = oracle.topk(s, k)
         assert np.array_equal(idx[0].cpu().numpy(), i)
         assert_bits_equal(vals[0].cpu().numpy(), v)
+    # the same on the full-sort path at its largest size, two images with different contents
+    n = 21504
+    s2 = rng.integers(-40, 41, (2, n)).astype(np.float32) * 0.25
+    s2[0, ::89] = np.nan
+    s2[1, 3::97] = -0.0
+    s2[1, 4::97] = 0.0
+    s2[0, 6::131] = np.inf
+    for k in (n // 2, 15000, n):
+        vals, idx = ops.topk_desc(T(s2, dev), k)
+        for b in range(2):
+            v, i = oracle.topk(s2[b], k)
+            assert np.array_equal(idx[b].cpu().numpy(), i)
+            assert_bits_equal(vals[b].cpu().numpy(), v)
 
 
 def test_rpn_stages_golden(dev):
@@ -420,6 +436,46 @@ def test_multiscale_roi_align_config5_scale(dev, oracle):
     out, total = pool.forward_padded(d, T(np.stack(props), dev), T([2000], dev, torch.int32), [(Himg, Wimg)])
     assert int(total) == 2000
     np.testing.assert_allclose(out[:2000].cpu().numpy(), ref, rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,H,W", [(20, 100, 168), (16, 70, 49), (5, 200, 336)])
+def test_roi_align_window_kernel_edges(dev, oracle, C, H, W):
+    """Planes too large for LDS (window kernel + direct kernel for the RoIs that fit no window): RoIs on
+    every border, a RoI wider than a window, one larger than the plane, degenerate ones, channel counts
+    that are and are not a multiple of 16, three images with different counts."""
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    rng = np.random.default_rng(C + H)
+    stride = 8
+    Himg, Wimg = H * stride, W * stride
+    B = 3
+    feat = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    props = []
+    for b, n in enumerate((97, 1, 40)):
+        s = rng.uniform(8, 200, (n, 2))
+        c = rng.uniform(0, 1, (n, 2)) * [Wimg, Himg]
+        bx = np.concatenate([c - s / 2, c + s / 2], 1)
+        bx[:, 0::2] = bx[:, 0::2].clip(0, Wimg)
+        bx[:, 1::2] = bx[:, 1::2].clip(0, Himg)
+        props.append(bx.astype(np.float32))
+    props[0][0] = [0, 0, 30, 30]                              # top-left corner
+    props[0][1] = [Wimg - 20, Himg - 25, Wimg, Himg]          # bottom-right corner
+    props[0][2] = [0, Himg - 40, 50, Himg]                    # bottom-left
+    props[0][3] = [100, 60, 100 + 47 * stride, 90]            # 47 cells wide: fits no window -> direct kernel
+    props[0][4] = [-50, -50, Wimg + 80, Himg + 80]            # larger than the plane
+    props[0][5] = [50, 50, 50, 50]                            # zero size -> roi_w = roi_h = 1
+    props[0][6] = [Wimg + 30, 10, Wimg + 60, 40]              # entirely right of the map: zeros
+    props[0][7] = [128, 128, 128 + 33 * stride - 1, 128 + 33 * stride - 1]   # just inside the window limit
+    props[0][8] = [120, 120, 120 + 34 * stride, 120 + 34 * stride]           # just outside it
+    ref, _ = oracle.multiscale_roi_align([feat], props, [(Himg, Wimg)], (7, 7), 2)
+    pool = ROIPooling(['1'], [7, 7], 2)
+    P = 97
+    padded = np.zeros((B, P, 4), np.float32)
+    for b, p in enumerate(props):
+        padded[b, :len(p)] = p
+    out, total = pool.forward_padded({'1': T(feat, dev)}, T(padded, dev), T([97, 1, 40], dev, torch.int32),
+                                     [(Himg, Wimg)])
+    assert int(total) == 138
+    np.testing.assert_allclose(out[:138].cpu().numpy(), ref, rtol=RTOL, atol=1e-5)
 
 
 def test_roi_pool_max_vs_oracle(dev, oracle):
