@@ -481,18 +481,17 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
         __syncthreads();
         // item = (RoI, bin): its tap addresses and weights are computed once and reused for every
         // channel group of the chunk.  A wave takes ONE whole RoI per iteration (lane = bin, 49 of
-        // 64 lanes busy) and owns a contiguous run of RoIs: its 16 channel stores then fill one
+        // 64 lanes busy): its 16 channel stores then fill one
         // 3136-byte (RoI, chunk) piece of the output back to back, which the memory system takes
         // 1.5x faster than the same bytes written as 64-item slices that straddle two RoIs and are
         // completed by another wave (tools/store_probe.hip, modes 16/20/23) -- worth more here than
         // the idle quarter of the lanes.  It also makes the level test, the zero fill and the
         // 3-tap choice below uniform per RoI.
-        const int rpw = (nseg + RAP_THREADS / 64 - 1) / (RAP_THREADS / 64);
-        const int ja = min(nseg, (int)(threadIdx.x >> 6) * rpw);
-        const int jb = min(nseg, ja + rpw);
+        // Wave w takes RoIs w, w+16, ...: at any time the 16 waves of the workgroup -- and, in step with
+        // them, the workgroups of the image's other channel chunks -- write 16 neighbouring output rows.
         const int bin = threadIdx.x & 63;
         const int ph = bin / 7, pw = bin - ph * 7;
-        for (int jl = ja; jl < (bin < 49 ? jb : ja); ++jl) { // lanes 49..63 sit the item loop out
+        for (int jl = (int)(threadIdx.x >> 6); jl < (bin < 49 ? nseg : 0); jl += RAP_THREADS / 64) { // lanes 49..63 idle
             const float4 rec = s_rec[jl];
             float *o = ob + (long long)(seg + jl) * C * 49 + bin;
             if (n_levels > 1) {
