@@ -333,6 +333,7 @@ def main():
             extras["serial"] = {k: ser[k] for k in ("value", "ms_per_step", "stage_ms")}
         extras.update(nms_microbench(path, dev))
         extras.update(next_rows_microbench(dev))
+        extras.update(hbm_probe(dev))
 
     if rank == 0:
         desc = {"realistic": "proposal-realistic deltas (NMS keeps 2000/img)",
@@ -359,6 +360,9 @@ def main():
             "gather_ms": gather_ms,
         }
         line.update(extras)
+        if "hbm_measured_GBps" in extras:  # the same launch against what a plain fill achieves on this device
+            line["roofline"]["frac_of_measured_fill"] = (line["roofline"]["achieved"] /
+                                                         extras["hbm_measured_GBps"]["write_only_fill"])
         if args.cpu_sample > 0 and world == 1:
             threads = min(os.cpu_count() or 1, 16)
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads, args.workload)
@@ -368,6 +372,29 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hbm_probe(dev):
+    """Achievable HBM rates on this device with plain streaming kernels (SURVEY 8d asks for them next to the
+    8 TB/s spec): a 2 GB write-only fill and a 1 GB -> 1 GB copy."""
+    n = 512 * 1024 * 1024
+    a = torch.empty(n, dtype=torch.float32, device=dev)
+    b = torch.empty(n // 2, dtype=torch.float32, device=dev)
+
+    def timed(fn, reps=5):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    fill = n * 4 / timed(lambda: a.fill_(1.0)) / 1e6
+    copy = n * 4 / timed(lambda: b.copy_(a[:n // 2])) / 1e6   # bytes read + written
+    del a, b
+    return {"hbm_measured_GBps": {"write_only_fill": fill, "copy_read_plus_write": copy}}
 
 
 def next_rows_microbench(dev):
