@@ -331,6 +331,7 @@ def main():
         if not args.serial:  # the same steps one after another on one stream: per-batch latency, stage times
             ser, _, _ = run_workload(path, dev, None, 0, 1, B, args.workload, max(5, args.steps // 2), 2, pipelined=False)
             extras["serial"] = {k: ser[k] for k in ("value", "ms_per_step", "stage_ms")}
+            extras["serial"]["roofline_frac"] = ser["roofline"]["frac"]  # the same launch with the chip to itself
         extras.update(nms_microbench(path, dev))
         extras.update(next_rows_microbench(dev))
         extras.update(hbm_probe(dev))
