@@ -62,14 +62,15 @@ __device__ __forceinline__ void frcnn_inter_union(float ax1, float ay1, float ax
                                                   float aarea, float bx1, float by1, float bx2,
                                                   float by2, float barea, float *inter, float *uni)
 {
-    float ltx = ax1 > bx1 ? ax1 : bx1;
-    float lty = ay1 > by1 ? ay1 : by1;
-    float rbx = ax2 < bx2 ? ax2 : bx2;
-    float rby = ay2 < by2 ? ay2 : by2;
-    float jw = rbx - ltx;
-    float jh = rby - lty;
-    jw = jw < 0.0f ? 0.0f : jw;
-    jh = jh < 0.0f ? 0.0f : jh;
+    // v_max_f32 / v_min_f32 (one instruction each instead of compare + select).  They drop a NaN operand
+    // where torch.max / torch.min would propagate it, which cannot change a decision: a box with a NaN
+    // coordinate has a NaN area, so `uni` is NaN and frcnn_iou_gt answers "not suppressed" either way.
+    float ltx = __builtin_fmaxf(ax1, bx1);
+    float lty = __builtin_fmaxf(ay1, by1);
+    float rbx = __builtin_fminf(ax2, bx2);
+    float rby = __builtin_fminf(ay2, by2);
+    float jw = __builtin_fmaxf(rbx - ltx, 0.0f);
+    float jh = __builtin_fmaxf(rby - lty, 0.0f);
     *inter = jw * jh;
     *uni = (aarea + barea) - *inter;
 }

@@ -266,10 +266,23 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
         const float carea = frcnn_area(cb.x, cb.y, cb.z, cb.w);
         bool sup = false;
         const int step = rsplit * 4;
-        for (int r = blockIdx.y * 4 + wave; r < nk; r += step) {
-            const float4 k = w.kbox[r];
+        int r = blockIdx.y * 4 + wave;
+        // the next kept box is fetched while the current one is tested
+        float4 k_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float a_next = 0.0f;
+        if (r < nk) {
+            k_next = w.kbox[r];
+            a_next = w.karea[r];
+        }
+        for (; r < nk; r += step) {
+            const float4 k = k_next;
+            const float ka = a_next;
+            if (r + step < nk) {
+                k_next = w.kbox[r + step];
+                a_next = w.karea[r + step];
+            }
             float inter, uni;
-            frcnn_inter_union(k.x, k.y, k.z, k.w, w.karea[r], cb.x, cb.y, cb.z, cb.w, carea, &inter, &uni);
+            frcnn_inter_union(k.x, k.y, k.z, k.w, ka, cb.x, cb.y, cb.z, cb.w, carea, &inter, &uni);
             sup = sup | frcnn_iou_gt(inter, uni, thr);
         }
         const unsigned long long m = __ballot(sup);
