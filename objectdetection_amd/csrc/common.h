@@ -92,7 +92,9 @@ __device__ __forceinline__ bool frcnn_iou_gt(float inter, float uni, const Frcnn
 {
     const float p = th.t2 * uni;
     const float d = inter - p;
-    const bool sure = th.fast && (p > 1e-30f) && (p < 3.0e38f) && (fabsf(d) > p * 9.5367431640625e-07f);
+    // p = +inf or NaN (huge or non-finite union) fails the last comparison by itself: inf > inf and
+    // NaN > x are false
+    const bool sure = th.fast && (p > 1e-30f) && (fabsf(d) > p * 9.5367431640625e-07f);
     bool r = d > 0.0f;
     if (__builtin_expect(__any(!sure), 0)) { // wave-uniform: taken about once per 2^14 wave tests
         const bool slow = (inter / uni) > th.t;
