@@ -530,6 +530,63 @@ def test_roi_align_full_size_properties(dev, oracle):
     torch.testing.assert_close(outC[sel], torch.full_like(outC[sel], 3.25), rtol=1e-6, atol=0)
 
 
+def test_roi_align_shape_sweep(dev, oracle):
+    """Seeded sweep over plane sizes, channel counts, strides and pyramid depths: every dispatch of the batched
+    RoIAlign (16-, 8- and 4-channel LDS planes, the generic instantiation, windows, the direct kernel) against
+    the oracle."""
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    rng = np.random.default_rng(777)
+    cases = [  # (C, [(H, W) per level, fine to coarse], stride of the finest level)
+        (16, [(37, 62)], 16), (32, [(36, 64)], 16), (7, [(37, 62)], 16), (33, [(20, 30)], 32),
+        (16, [(48, 48)], 16), (16, [(49, 49)], 16), (12, [(64, 96)], 8), (40, [(75, 100)], 8),
+        (16, [(96, 128), (48, 64), (24, 32)], 8), (24, [(128, 200), (64, 100), (32, 50), (16, 25)], 4),
+        (3, [(8, 8)], 32), (64, [(1, 1)], 64), (16, [(2, 70)], 16),
+    ]
+    for C, fsz, stride in cases:
+        B = int(rng.integers(1, 4))
+        Himg, Wimg = fsz[0][0] * stride, fsz[0][1] * stride
+        feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for h, w in fsz]
+        counts = [int(rng.integers(0, 60)) for _ in range(B)]
+        counts[int(rng.integers(0, B))] = 60
+        props = []
+        for n in counts:
+            s = np.exp(rng.uniform(np.log(4), np.log(max(Himg, Wimg) * 1.2), (n, 2)))
+            c = rng.uniform(-0.1, 1.1, (n, 2)) * [Wimg, Himg]
+            props.append(np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32))
+        names = [str(i + 1) for i in range(len(fsz))]
+        ref, _ = oracle.multiscale_roi_align(feats, props, [(Himg, Wimg)], (7, 7), 2)
+        pool = ROIPooling(names, [7, 7], 2)
+        P = 60
+        padded = np.zeros((B, P, 4), np.float32)
+        for b, p in enumerate(props):
+            padded[b, :len(p)] = p
+        d = {k: T(f, dev) for k, f in zip(names, feats)}
+        out, total = pool.forward_padded(d, T(padded, dev), T(counts, dev, torch.int32), [(Himg, Wimg)])
+        assert int(total) == sum(counts), (C, fsz)
+        np.testing.assert_allclose(out[:sum(counts)].cpu().numpy(), ref, rtol=RTOL, atol=2e-5,
+                                   err_msg="C=%d planes=%s stride=%d" % (C, fsz, stride))
+        got = pool(d, [T(p, dev) for p in props], [(Himg, Wimg)])      # the reference's list API
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=2e-5)
+
+
+def test_nms_size_sweep(dev, oracle):
+    """Seeded sweep over candidate counts around the lazy / round boundaries and keep budgets."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(4242)
+    for n, max_keep, thr in [(1, 5, 0.5), (63, 63, 0.3), (64, 10, 0.7), (65, 65, 0.7), (1023, 1000, 0.5),
+                             (1024, 2000, 0.7), (1025, 17, 0.7), (2048, 2000, 0.6), (2049, 2049, 0.7),
+                             (3000, 1, 0.7), (4097, 300, 0.45), (9000, 2000, 0.7)]:
+        B = 3
+        boxes = np.stack([realistic_boxes(rng, n, 800, 600) for _ in range(B)])
+        counts = np.asarray([n, max(1, n // 2), n - 1 if n > 1 else 1], np.int32)
+        keep, nk = ops.nms_sorted(T(boxes, dev), T(counts, dev, torch.int32), thr, max_keep)
+        for b in range(B):
+            c = int(counts[b])
+            ref = oracle.nms(boxes[b, :c], np.arange(c, 0, -1, dtype=np.float32), thr)[:max_keep]
+            assert int(nk[b]) == len(ref), (n, max_keep, thr, b)
+            assert np.array_equal(keep[b, :len(ref)].cpu().numpy(), ref), (n, max_keep, thr, b)
+
+
 def test_roi_pool_max_vs_oracle(dev, oracle):
     from objectdetection_amd import ops
     rng = np.random.default_rng(11)
