@@ -805,6 +805,52 @@ def test_generalized_transform_golden(dev):
     assert_bits_equal(batch.cpu().numpy(), g["pad.batch"])
 
 
+def test_proposal_path_full_size_properties(dev, oracle):
+    """BASELINE config 2 at full size (batch 16, A = 20,646, k = 12,000, keep 2,000) on the bench's inputs:
+    top-k is sorted and is exactly the k largest; NMS keeps are in candidate order, mutually below the
+    threshold, and every earlier candidate that was dropped has a kept suppressor before it (the defining
+    properties of greedy NMS); two images are also checked against the oracle outright."""
+    import bench
+    from objectdetection_amd import ops
+    B = 16
+    cls, reg, feat = (t.to(dev) for t in bench.make_batch(100, B, "realistic"))
+    path = bench.Path(dev)
+    anchors = path.anchors(B, feat)
+    scores, deltas = ops.rpn_flatten([cls], [reg])
+    top_val, top_idx = ops.topk_desc(scores, bench.PRE_NMS)
+    # top-k: sorted descending, values are the gathered scores, nothing outside beats the k-th
+    assert bool((top_val[:, :-1] >= top_val[:, 1:]).all())
+    assert torch.equal(torch.gather(scores, 1, top_idx.long()), top_val)
+    kth = top_val[:, -1:]
+    assert int((scores > kth).sum()) == int((top_val > kth).sum())
+    boxes, fscores, src, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, bench.IMG_H, bench.IMG_W,
+                                                       bench.MIN_SIZE)
+    keep, n_keep = ops.nms_sorted(boxes, count, bench.NMS_THR, bench.POST_NMS)
+    for b in range(B):
+        c, nk = int(count[b]), int(n_keep[b])
+        kp = keep[b, :nk].long()
+        assert bool((kp[1:] > kp[:-1]).all()) and int(kp[-1]) < c
+        kept = boxes[b, kp]
+        iou = ops.box_iou(kept, kept).double()
+        iou.fill_diagonal_(0)
+        assert not bool((iou > bench.NMS_THR).any())
+        if nk < bench.POST_NMS:
+            last = c
+        else:
+            last = int(kp[-1])            # the scan stopped here: candidates after it were never looked at
+        dropped = torch.ones(last, dtype=torch.bool, device=dev)
+        dropped[kp[kp < last]] = False
+        cand = torch.nonzero(dropped)[:, 0]
+        if cand.numel():
+            ci = ops.box_iou(boxes[b, cand], kept).double()
+            earlier = kp[None, :] < cand[:, None]
+            assert bool(((ci > bench.NMS_THR) & earlier).any(dim=1).all())
+    for b in (3, 11):
+        c = int(count[b])
+        ref = oracle.nms(boxes[b, :c].cpu().numpy(), fscores[b, :c].cpu().numpy(), bench.NMS_THR)[:bench.POST_NMS]
+        assert np.array_equal(keep[b, :int(n_keep[b])].cpu().numpy(), ref)
+
+
 def test_determinism(dev):
     """Same input twice -> identical bits (no atomics-order dependence anywhere on the path)."""
     from objectdetection_amd import ops
