@@ -441,6 +441,26 @@ def next_rows_microbench(dev):
     reg_label = torch.randn(N, 4, generator=g).to(dev)
     ms = timed(lambda: ops.roi_loss(logits, pred, cls_label, reg_label))
     res["roi_loss_fwd_bwd"] = {"ms": ms, "rows": N, "algorithmic_bytes": N * (Kc * 20 * 2 + 20)}
+    # row 1: ROIHead eval post-process, 16 x 2,000 proposals x 21 classes (filter -> sort -> NMS), device part
+    Pn, Kc2 = 2000, 21
+    pr = torch.rand(B * Pn, 4, generator=g) * 400
+    pr[:, 2:] += pr[:, :2] + 8
+    pr = pr.to(dev)
+    rg = (torch.randn(B * Pn, Kc2 * 4, generator=g) * 0.2).to(dev)
+    sc = torch.softmax(torch.randn(B * Pn, Kc2, generator=g) * 3, -1).to(dev)
+    row_off = torch.arange(0, (B + 1) * Pn, Pn, dtype=torch.int32, device=dev)
+    sizes = torch.tensor([[float(IMG_H), float(IMG_W)]] * B, device=dev)
+
+    def post():
+        bx, s2, lb, cnt = ops.roi_detect_filter(pr, rg, sc, row_off, sizes, Pn, 0.5, 1e-3)
+        vmax = 4096  # fixed candidate budget for the timing (the module reads the true maximum from the device)
+        _, order = ops.topk_desc(s2[:, :vmax].contiguous(), vmax, want_values=False)
+        sb = ops.gather_boxes(bx, order, cnt)
+        return ops.nms_sorted(sb, cnt, 0.5, 100)
+
+    ms = timed(post)
+    res["roi_head_eval_postprocess"] = {"ms": ms, "candidates": B * Pn * Kc2,
+                                        "algorithmic_bytes": B * Pn * Kc2 * 4 + B * Pn * 16}
     # row 4: decode backward on the batch's 16 x 12,000 candidates
     n = B * PRE_NMS
     box = torch.rand(n, 4, generator=g).to(dev) * 500

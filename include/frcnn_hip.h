@@ -174,6 +174,19 @@ int frcnn_roi_pool_f32(const float *feat, int B, int C, int H, int W, const floa
                        int pooled_h, int pooled_w, float spatial_scale, float *out, int32_t *argmax,
                        void *stream);
 
+/* ---- ROIHead eval post-process ---------------------------------------------
+ * ROIHead/roi_head.py:178-209 for a whole batch in one launch.  props: (N,4) the images' proposal
+ * lists concatenated; regs: (N,K,4); scores: (N,K) (softmax output); row_off: (B+1) int32 device,
+ * rows of image b are [row_off[b], row_off[b+1]), at most max_rows of them; image_sizes: (B,2)
+ * fp32 device (h, w).  Candidate (j, c) of an image is decoded (box_regression), clipped to that
+ * image's size and kept when score > score_thresh, w > min_size, h > min_size and c > 0, in the
+ * reference's flat order j*K + c.  Outputs are (B, max_rows*K[,4]) with the first count_out[b]
+ * rows of each image valid: boxes, scores, labels (int32 class ids). */
+int frcnn_roi_detect_filter_f32(const float *props, const float *regs, const float *scores,
+                                const int32_t *row_off, const float *image_sizes, int B, int K,
+                                int max_rows, float score_thresh, float min_size, float *boxes_out,
+                                float *scores_out, int32_t *labels_out, int32_t *count_out, void *stream);
+
 /* ---- sampled-gather + losses ---------------------------------------------
  * RPN/rpn.py:122-137 in one launch: rows `index[s]` (flat b*A+a, S of them, negatives first) are
  * gathered from scores (rows), regs (rows,4), labels (rows), reg_labels (rows,4);

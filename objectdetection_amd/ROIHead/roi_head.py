@@ -93,24 +93,32 @@ class ROIHead(Module):
             # roi_head.py:167-229
             num_class = predict_cls.size(-1)
             predict_score = F.softmax(predict_cls, -1)
+            # One launch decodes / clips / filters every (proposal, class) candidate of the batch
+            # (:178-209), one sort + gather + NMS pass handles all images (:215), and the host reads two
+            # small count vectors instead of synchronising four times per image.
             num_per_image = [p.size(0) for p in list_rpn_proposals]
-            list_score = torch.split(predict_score, num_per_image)
-            list_reg = torch.split(predict_reg, num_per_image)
-            for i in range(len(list_rpn_proposals)):
-                proposal = list_rpn_proposals[i]
-                score = list_score[i]
-                label = torch.arange(num_class, device=device)[None, :].expand_as(score)
-                proposal = ops.box_regression(proposal, list_reg[i].flatten(1, 2)).view(-1, 4)
-                proposal = ops.box_clip(proposal, list_image_size[i][0], list_image_size[i][1])
-                score = score.detach().flatten()
-                label = label.flatten()
-                index, count = ops.select_gt(score, self.score_thresh)               # roi_head.py:197
-                index = index[:int(count.item())]
-                proposal, score, label = proposal[index], score[index], label[index]
-                _, index = remove_small_box(proposal, self.proposal_min_size)         # roi_head.py:203
-                proposal, score, label = proposal[index], score[index], label[index]
-                index = torch.where(torch.gt(label, 0))[0]                            # roi_head.py:209
-                proposal, score, label = proposal[index], score[index], label[index]
-                index = ops.nms(proposal, score, self.nms_threshold)[:self.num_post_nms]  # roi_head.py:215
-                result.append({'proposal': proposal[index], 'score': score[index], 'label': label[index]})
+            B = len(list_rpn_proposals)
+            row_off = torch.tensor([0] + list(torch.tensor(num_per_image).cumsum(0).tolist()), dtype=torch.int32,
+                                   device=device)
+            sizes = torch.tensor([[float(s[0]), float(s[1])] for s in list_image_size], dtype=torch.float32,
+                                 device=device)
+            boxes, scores, labels, count = ops.roi_detect_filter(
+                torch.cat(list_rpn_proposals), predict_reg.detach(), predict_score.detach(), row_off, sizes,
+                max(num_per_image) if num_per_image else 0, self.score_thresh, self.proposal_min_size)
+            counts = count.tolist()                                   # host read 1: candidates per image
+            vmax = max(counts) if counts else 0
+            if vmax > 0:
+                valid = torch.arange(vmax, device=device)[None, :] < count[:, None]
+                padded = torch.where(valid, scores[:, :vmax], torch.full_like(scores[:, :vmax], float("-inf")))
+                _, order = ops.topk_desc(padded, vmax, want_values=False)          # descending score, ties by index
+                sorted_boxes = ops.gather_boxes(boxes, order, count)
+                keep, n_keep = ops.nms_sorted(sorted_boxes, count, self.nms_threshold, self.num_post_nms)
+                n_kept = n_keep.tolist()                              # host read 2: detections per image
+            for i in range(B):
+                if vmax > 0 and n_kept[i] > 0:
+                    index = order[i, keep[i, :n_kept[i]].long()].long()
+                else:
+                    index = torch.empty((0,), dtype=torch.int64, device=device)
+                result.append({'proposal': boxes[i, index], 'score': scores[i, index],
+                               'label': labels[i, index].long()})
         return result, roi_loss

@@ -353,6 +353,95 @@ extern "C" int frcnn_decode_clip_filter_f32(const float *anchors, int64_t anchor
     return FRCNN_OK;
 }
 
+// ---- ROIHead eval post-process, batched (ROIHead/roi_head.py:178-209) ---------------------------
+// For every image at once: per (proposal j, class c) candidate, in the reference's flat order j*K + c:
+// decode the class's deltas against the proposal (utils.box_regression), clip to the image's own
+// size, and keep it when score > score_thresh (:197), w > min_size and h > min_size (:203) and c > 0
+// (:209).  The three filters of the reference are order-preserving and each looks at one candidate
+// only, so applying them as one predicate gives the same list.  Workgroup = (tile of 1024
+// candidates, image); as in decode_clip_filter_kernel a tile re-derives the keep count of the tiles
+// before it -- cheaply, because almost every candidate already fails the score test, which needs no
+// decode.
+__device__ __forceinline__ bool detect_keep(const float4 *__restrict__ props, const float4 *__restrict__ regs,
+                                            const float *__restrict__ scores, long long row0, int m, int K,
+                                            float image_h, float image_w, float score_thresh, float min_size,
+                                            float4 *box_out, float *score_out)
+{
+    const int j = m / K, c = m - j * K;
+    const long long e = (row0 + j) * K + c;
+    const float sc = scores[e];
+    *score_out = sc;
+    if (!(c > 0 && sc > score_thresh)) return false;
+    float4 p = clip_box(decode_one(props[row0 + j], regs[e], (float)FRCNN_DW_CLAMP), image_h, image_w);
+    *box_out = p;
+    return (p.z - p.x > min_size) && (p.w - p.y > min_size);
+}
+
+__global__ void __launch_bounds__(1024)
+roi_detect_filter_kernel(const float4 *__restrict__ props, const float4 *__restrict__ regs,
+                         const float *__restrict__ scores, const int32_t *__restrict__ row_off,
+                         const float *__restrict__ image_sizes, int K, float score_thresh, float min_size,
+                         int cap, float4 *__restrict__ boxes_out, float *__restrict__ scores_out,
+                         int32_t *__restrict__ labels_out, int32_t *__restrict__ count_out)
+{
+    __shared__ int wave_sums[16];
+    __shared__ int s_prior[16];
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;
+    const long long row0 = row_off[b];
+    const int M = (row_off[b + 1] - row_off[b]) * K; // candidates of this image
+    if (tile * 1024 >= M && tile != 0) return;       // (tile 0 still reports a zero count)
+    const float image_h = image_sizes[2 * b], image_w = image_sizes[2 * b + 1];
+    int prior = 0;
+    for (int u = 0; u < tile; ++u) {
+        float4 q;
+        float sc;
+        prior += detect_keep(props, regs, scores, row0, u * 1024 + (int)threadIdx.x, K, image_h, image_w,
+                             score_thresh, min_size, &q, &sc) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) prior += __shfl_down(prior, o);
+    if ((threadIdx.x & 63) == 0) s_prior[threadIdx.x >> 6] = prior;
+    const int m = tile * 1024 + threadIdx.x;
+    float4 p = make_float4(0, 0, 0, 0);
+    float sc = 0.0f;
+    const bool keep = m < M && detect_keep(props, regs, scores, row0, m, K, image_h, image_w, score_thresh,
+                                           min_size, &p, &sc);
+    int tot;
+    int pos = frcnn_block_excl_count(keep, wave_sums, &tot); // (its barriers also publish s_prior)
+    int base = 0;
+    for (int w = 0; w < 16; ++w) base += s_prior[w];
+    pos += base;
+    if (keep) {
+        boxes_out[(long long)b * cap + pos] = p;
+        scores_out[(long long)b * cap + pos] = sc;
+        labels_out[(long long)b * cap + pos] = m % K;
+    }
+    if (threadIdx.x == 0 && (tile + 1) * 1024 >= M) count_out[b] = base + tot; // the image's last tile
+}
+
+extern "C" int frcnn_roi_detect_filter_f32(const float *props, const float *regs, const float *scores,
+                                           const int32_t *row_off, const float *image_sizes, int B, int K,
+                                           int max_rows, float score_thresh, float min_size, float *boxes_out,
+                                           float *scores_out, int32_t *labels_out, int32_t *count_out,
+                                           void *stream)
+{
+    FRCNN_REQUIRE(B > 0 && B <= 65535 && K > 0 && max_rows >= 0, "roi_detect_filter: bad shape");
+    FRCNN_REQUIRE((long long)max_rows * K < (1ll << 30), "roi_detect_filter: too many candidates per image");
+    FRCNN_REQUIRE(row_off && image_sizes && count_out, "roi_detect_filter: null pointer");
+    const int cap = max_rows * K;
+    if (cap == 0) {
+        hipError_t e = hipMemsetAsync(count_out, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
+        FRCNN_REQUIRE(e == hipSuccess, "roi_detect_filter: memset failed: %s", hipGetErrorString(e));
+        return FRCNN_OK;
+    }
+    FRCNN_REQUIRE(props && regs && scores && boxes_out && scores_out && labels_out, "roi_detect_filter: null pointer");
+    hipLaunchKernelGGL(roi_detect_filter_kernel, dim3((cap + 1023) / 1024, B), dim3(1024), 0, (hipStream_t)stream,
+                       (const float4 *)props, (const float4 *)regs, scores, row_off, image_sizes, K, score_thresh,
+                       min_size, cap, (float4 *)boxes_out, scores_out, labels_out, count_out);
+    FRCNN_CHECK_LAUNCH("roi_detect_filter");
+    return FRCNN_OK;
+}
+
 // ---- gather -----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gather_boxes_kernel(const float4 *__restrict__ src,
                                                            const int32_t *__restrict__ idx,

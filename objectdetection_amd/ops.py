@@ -180,6 +180,33 @@ def resize_pad_into(image, out_h, out_w, canvas):
     return canvas
 
 
+def roi_detect_filter(props, regs, scores, row_off, image_sizes, max_rows, score_thresh, min_size):
+    """ROIHead/roi_head.py:178-209 for a batch: props (N,4) concatenated, regs (N,K,4) or (N,4K), scores (N,K),
+    row_off (B+1) int32, image_sizes (B,2) fp32 (h,w).  -> boxes (B,M,4), scores (B,M), labels (B,M) int32,
+    count (B) int32 with M = max_rows*K; the first count[b] rows of image b are its kept candidates in flat order."""
+    _need_gpu(props, regs, scores, row_off, image_sizes)
+    props, regs, scores = _f32c(props), _f32c(regs), _f32c(scores)
+    image_sizes = _f32c(image_sizes)
+    row_off = row_off.to(torch.int32).contiguous()
+    N, K = scores.shape
+    if props.shape != (N, 4) or regs.numel() != N * K * 4 or image_sizes.shape != (row_off.numel() - 1, 2):
+        raise ValueError("roi_detect_filter: inconsistent shapes")
+    B = row_off.numel() - 1
+    M = int(max_rows) * K
+    dev = scores.device
+    boxes = torch.empty((B, M, 4), dtype=torch.float32, device=dev)
+    sc = torch.empty((B, M), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, M), dtype=torch.int32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().frcnn_roi_detect_filter_f32(_ptr(props), _ptr(regs), _ptr(scores), _ptr(row_off),
+                                                     _ptr(image_sizes), B, K, int(max_rows), float(score_thresh),
+                                                     float(min_size), _ptr(boxes), _ptr(sc), _ptr(labels), _ptr(count),
+                                                     _stream())
+    _lib.check(rc, "roi_detect_filter")
+    return boxes, sc, labels, count
+
+
 SMOOTH_L1_BETA = 1.0 / 9  # utils.py:315
 
 

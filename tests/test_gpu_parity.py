@@ -742,6 +742,69 @@ def test_roi_head_eval_and_targets(dev, oracle):
     assert set(loss2) == {"cls_loss", "reg_loss"}
 
 
+def test_roi_head_eval_postprocess_vs_oracle(dev, oracle):
+    """SURVEY 8f row 1, batched: ROIHead.forward (eval) with fixed predictor outputs against the reference's
+    per-image sequence restated with the oracle (roi_head.py:167-229: softmax, per-class box_regression,
+    clip to each image's own size, score > thresh, small-box filter, label > 0, class-agnostic NMS, cut)."""
+    from objectdetection_amd.ROIHead import ROIHead, ROIPooling
+    rng = np.random.default_rng(99)
+    K, Cf = 7, 4
+    info = (3, 256, 320)
+    sizes = [(250, 300), (256, 320), (200, 310)]
+    nprops = [150, 1, 333]
+    feats = [torch.rand(3, Cf, 32, 40, device=dev)]
+    props = [realistic_boxes(rng, n, 320, 256) for n in nprops]
+    N = sum(nprops)
+    logits = (rng.standard_normal((N, K)) * 2.5).astype(np.float32)
+    regs = (rng.standard_normal((N, K * 4)) * 0.3).astype(np.float32)
+    regs[5, 10] = 9.0      # above the dw clamp
+    regs[7, 8:12] = [0, 0, -40, -40]   # collapses: dropped by the small-box filter
+
+    class Flat(torch.nn.Module):
+        def forward(self, x):
+            return x.flatten(1)
+
+    class Fixed(torch.nn.Module):
+        def forward(self, x):
+            return T(logits, dev), T(regs, dev)
+
+    params = dict(pos_threshold=0.5, neg_threshold=0.5, num_sample=128, pos_fraction=0.25,
+                  regression_weights=[10., 10., 5., 5.], score_thresh=0.05, proposal_min_size=1e-3,
+                  nms_threshold=0.5, num_post_nms=40, roi_pooling=ROIPooling(['1'], [7, 7], 2), mlp_head=Flat(),
+                  predictor=Fixed())
+    head = ROIHead(params)
+    result, loss = head([T(p, dev) for p in props], feats, info, None, sizes)
+    assert loss == {} and len(result) == 3
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    prob = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    off = 0
+    total_det = 0
+    for i, n in enumerate(nprops):
+        sc = torch.softmax(torch.as_tensor(logits[off:off + n]), -1).numpy().reshape(-1)     # same fp32 softmax as torch's
+        box = oracle.box_clip(oracle.box_regression(props[i], regs[off:off + n]).reshape(-1, 4), sizes[i])
+        lab = np.tile(np.arange(K), n)
+        m = sc > np.float32(0.05)
+        box, s2, lab = box[m], sc[m], lab[m]
+        _, idx = oracle.remove_small_box(box, 1e-3)
+        box, s2, lab = box[idx], s2[idx], lab[idx]
+        m = lab > 0
+        box, s2, lab = box[m], s2[m], lab[m]
+        got = result[i]
+        g_box, g_sc, g_lab = got['proposal'].cpu().numpy(), got['score'].cpu().numpy(), got['label'].cpu().numpy()
+        assert got['label'].dtype == torch.int64
+        if len(box) == 0:
+            assert len(g_sc) == 0
+        else:
+            keep = oracle.nms(box, s2, 0.5)[:40]
+            assert len(g_sc) == len(keep), (i, len(g_sc), len(keep))
+            np.testing.assert_allclose(g_sc, s2[keep], rtol=1e-6)
+            assert np.array_equal(g_lab, lab[keep])
+            np.testing.assert_allclose(g_box, box[keep], rtol=RTOL, atol=1e-4)
+            total_det += len(keep)
+        off += n
+    assert total_det > 20
+
+
 def test_sampled_losses_golden(dev, oracle):
     """fused gather + loss kernels against what torch / the reference's smooth_l1_loss
     produced (losses.npz), gradients through autograd included, and against the CPU restatement."""
