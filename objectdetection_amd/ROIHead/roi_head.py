@@ -64,9 +64,23 @@ class ROIHead(Module):
         list_cls_label, list_reg_label, list_proposals = [], [], []
         if self.training:
             targets = self.proposal_targets(list_rpn_proposals, list_targets, device)
-            for proposal, (cls_label, reg_label) in zip(list_rpn_proposals, targets):
-                pos_index = torch.where(torch.gt(cls_label, 0))[0]                 # roi_head.py:113
-                neg_index = torch.where(torch.eq(cls_label, 0))[0]                 # roi_head.py:114
+            # roi_head.py:113-114 for the whole batch: two nonzero calls on the padded label matrix (row-major:
+            # each image's indices are contiguous and ascending) instead of two host syncs per image
+            n_img = len(list_rpn_proposals)
+            p_max = max(p.shape[0] for p in list_rpn_proposals)
+            lab_pad = torch.full((n_img, p_max), -1.0, dtype=torch.float32, device=device)
+            for i, (cls_label, _) in enumerate(targets):
+                lab_pad[i, :cls_label.shape[0]] = cls_label
+            pos_all = torch.nonzero(torch.gt(lab_pad, 0))
+            neg_all = torch.nonzero(torch.eq(lab_pad, 0))
+            pos_cnt = torch.bincount(pos_all[:, 0], minlength=n_img).tolist()
+            neg_cnt = torch.bincount(neg_all[:, 0], minlength=n_img).tolist()
+            pos_off = neg_off = 0
+            for i, (proposal, (cls_label, reg_label)) in enumerate(zip(list_rpn_proposals, targets)):
+                pos_index = pos_all[pos_off:pos_off + pos_cnt[i], 1]
+                neg_index = neg_all[neg_off:neg_off + neg_cnt[i], 1]
+                pos_off += pos_cnt[i]
+                neg_off += neg_cnt[i]
                 pos_factor, neg_factor = get_sampling_factor(self.num_sample, self.pos_fraction,
                                                              pos_index.size(0), neg_index.size(0))
                 random_index = torch.cat([neg_index[neg_factor.to(device)], pos_index[pos_factor.to(device)]])

@@ -88,11 +88,19 @@ class RPN(Module):
                              dim=1)
             labels, reg_labels = self.anchor_targets(anchors, list_targets, device)
             A = scores.shape[1]
+            # rpn.py:115-116 for the whole batch: two nonzero calls (row-major, so each image's indices are
+            # contiguous and ascending) instead of two host synchronisations per image
+            neg_all = torch.nonzero(torch.eq(labels, 0))
+            pos_all = torch.nonzero(torch.eq(labels, 1))
+            neg_cnt = torch.bincount(neg_all[:, 0], minlength=batch_size).tolist()
+            pos_cnt = torch.bincount(pos_all[:, 0], minlength=batch_size).tolist()
             list_index = []
+            neg_off = pos_off = 0
             for b in range(batch_size):
-                cls_label = labels[b]
-                neg_index = torch.where(torch.eq(cls_label, 0))[0]                # rpn.py:115
-                pos_index = torch.where(torch.eq(cls_label, 1))[0]                # rpn.py:116
+                neg_index = neg_all[neg_off:neg_off + neg_cnt[b], 1]
+                pos_index = pos_all[pos_off:pos_off + pos_cnt[b], 1]
+                neg_off += neg_cnt[b]
+                pos_off += pos_cnt[b]
                 pos_factor, neg_factor = get_sampling_factor(self.num_sample, self.pos_fraction,
                                                              pos_index.size(0), neg_index.size(0))
                 random_index = torch.cat([neg_index[neg_factor.to(device)], pos_index[pos_factor.to(device)]])
