@@ -104,7 +104,6 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_cnt[TOPK_WAVES][256];
     __shared__ unsigned s_digit_base[256];
-    __shared__ int s_wave_sums[16];
     __shared__ unsigned s_prefix, s_remaining;
 
     const int tid = threadIdx.x;
@@ -122,16 +121,21 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
     for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) s_hist[tid] = 0;
         __syncthreads();
-        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
-            int i = i0 + tid;
-            bool act = false;
-            unsigned dg = 0;
-            if (i < n) {
-                unsigned key = frcnn_score_key(sc[i]);
-                act = (key & mask) == prefix;
-                dg = (key >> shift) & 255u;
+        for (int i0 = 0; i0 < n; i0 += 4 * TOPK_THREADS) { // four rounds of loads in flight
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * TOPK_THREADS + tid;
+                v[u] = i < n ? sc[i] : 0.0f;
             }
-            wave_hist_add(s_hist, dg, act);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * TOPK_THREADS + tid;
+                const unsigned key = frcnn_score_key(v[u]);
+                const bool act = i < n && (key & mask) == prefix;
+                const unsigned dg = (key >> shift) & 255u;
+                if (__any(act)) wave_hist_add(s_hist, dg, act); // after the first pass few waves hold a candidate
+            }
         }
         __syncthreads();
         if (wave == 0) {
@@ -167,29 +171,60 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
     const unsigned T = prefix;        // key of the k-th largest
     const unsigned need_eq = remaining; // how many elements with key == T are selected (lowest idx)
 
-    // ---- 2. index-ordered compaction of the k winners into (keyA, idxA)
+    // ---- 2. index-ordered compaction of the k winners into (keyA, idxA).  A wave owns a contiguous
+    // index range: it first counts its winners, one barrier publishes the 16 counts, then it writes
+    // its range with ballot ranks -- no barrier per round of 1024 elements.
     {
-        int base = 0, eq_base = 0;
-        for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
-            int i = i0 + tid;
-            unsigned key = 0;
-            bool gt = false, eq = false;
-            if (i < n) {
-                key = frcnn_score_key(sc[i]);
-                gt = key > T;
-                eq = key == T;
+        __shared__ int s_wgt[TOPK_WAVES], s_weq[TOPK_WAVES];
+        const int wseg = ((n + TOPK_WAVES - 1) / TOPK_WAVES + 63) / 64 * 64;
+        const int lo = min(wave * wseg, n), hi = min(lo + wseg, n);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int cg = 0, ce = 0;
+        for (int e0 = lo; e0 < hi; e0 += 256) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = e0 + u * 64 + lane < hi ? sc[e0 + u * 64 + lane] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = e0 + u * 64 + lane;
+                const unsigned key = frcnn_score_key(v[u]);
+                cg += __popcll(__ballot(i < hi && key > T));
+                ce += __popcll(__ballot(i < hi && key == T));
             }
-            int eq_tot;
-            int eq_rank = eq_base + frcnn_block_excl_count(eq, s_wave_sums, &eq_tot);
-            bool sel = gt || (eq && (unsigned)eq_rank < need_eq);
-            int tot;
-            int pos = base + frcnn_block_excl_count(sel, s_wave_sums, &tot);
-            if (sel) {
-                keyA[pos] = key;
-                idxA[pos] = (uint32_t)i;
+        }
+        if (lane == 0) {
+            s_wgt[wave] = cg;
+            s_weq[wave] = ce;
+        }
+        __syncthreads();
+        int gt_before = 0, eq_before = 0;
+        for (int w = 0; w < wave; ++w) {
+            gt_before += s_wgt[w];
+            eq_before += s_weq[w];
+        }
+        int base = gt_before + min(eq_before, (int)need_eq); // winners at lower indices
+        for (int e0 = lo; e0 < hi; e0 += 256) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = e0 + u * 64 + lane < hi ? sc[e0 + u * 64 + lane] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = e0 + u * 64 + lane;
+                const unsigned key = frcnn_score_key(v[u]);
+                const bool gt = i < hi && key > T;
+                const bool eq = i < hi && key == T;
+                const unsigned long long meq = __ballot(eq);
+                const int eq_rank = eq_before + __popcll(meq & lt);
+                const bool sel = gt || (eq && (unsigned)eq_rank < need_eq);
+                const unsigned long long msel = __ballot(sel);
+                if (sel) {
+                    const int pos = base + __popcll(msel & lt);
+                    keyA[pos] = key;
+                    idxA[pos] = (uint32_t)i;
+                }
+                base += __popcll(msel);
+                eq_before += __popcll(meq);
             }
-            base += tot;
-            eq_base += eq_tot;
         }
     }
     __syncthreads();
@@ -202,11 +237,17 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
     for (int shift = 0; shift < 32; shift += 8) {
         for (int t = tid; t < TOPK_WAVES * 256; t += TOPK_THREADS) (&s_cnt[0][0])[t] = 0;
         __syncthreads();
-        for (int e0 = seg_lo; e0 < seg_hi; e0 += 64) {
-            int e = e0 + lane;
-            bool act = e < seg_hi;
-            unsigned dg = act ? 255u - ((kin[e] >> shift) & 255u) : 0u;
-            wave_hist_add(s_cnt[wave], dg, act);
+        for (int e0 = seg_lo; e0 < seg_hi; e0 += 256) {
+            unsigned kk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kk[u] = e0 + u * 64 + lane < seg_hi ? kin[e0 + u * 64 + lane] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e0 + u * 64 < seg_hi) { // wave-uniform
+                    const bool act = e0 + u * 64 + lane < seg_hi;
+                    wave_hist_add(s_cnt[wave], 255u - ((kk[u] >> shift) & 255u), act);
+                }
+            }
         }
         __syncthreads();
         // per digit: exclusive prefix over waves, digit totals -> s_hist
@@ -236,11 +277,20 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
             s_digit_base[4 * lane + 3] = excl + v0 + v1 + v2;
         }
         __syncthreads();
-        for (int e0 = seg_lo; e0 < seg_hi; e0 += 64) {
-            int e = e0 + lane;
-            bool act = e < seg_hi;
-            unsigned key = act ? kin[e] : 0u;
-            unsigned idx = act ? iin[e] : 0u;
+        for (int e0 = seg_lo; e0 < seg_hi; e0 += 256) {
+          unsigned kk[4], ii[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+              const bool a = e0 + u * 64 + lane < seg_hi;
+              kk[u] = a ? kin[e0 + u * 64 + lane] : 0u;
+              ii[u] = a ? iin[e0 + u * 64 + lane] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (e0 + u * 64 >= seg_hi) break; // wave-uniform
+            bool act = e0 + u * 64 + lane < seg_hi;
+            unsigned key = kk[u];
+            unsigned idx = ii[u];
             unsigned dg = 255u - ((key >> shift) & 255u);
             unsigned long long peers = wave_match8(dg, act);
             if (act) {
@@ -254,6 +304,7 @@ topk_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ 
                 iout[pos] = idx;
                 if (rank == 0) wcnt[dg] = off + (unsigned)__popcll(peers);
             }
+          }
         }
         __syncthreads();
         uint32_t *tk = kin; kin = kout; kout = tk;
