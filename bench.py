@@ -334,6 +334,8 @@ def main():
             extras["serial"]["roofline_frac"] = ser["roofline"]["frac"]  # the same launch with the chip to itself
         extras.update(nms_microbench(path, dev))
         extras.update(next_rows_microbench(dev))
+        extras.update(targets_microbench(path, dev))
+        extras.update(config5_microbench(dev))
         extras.update(hbm_probe(dev))
 
     if rank == 0:
@@ -470,6 +472,137 @@ def next_rows_microbench(dev):
     ms = timed(lambda: ops.box_regression_backward(box, dl, up))
     res["decode_backward"] = {"ms": ms, "rows": n, "algorithmic_bytes": n * 80, "GBps": n * 80 / ms / 1e6}
     return {"next_rows": res}
+
+
+def targets_microbench(path, dev):
+    """training targets for a batch of 16.  AnchorTarget = tagging_box + box_deviation of
+    A = 20,646 anchors against M = 100 boxes per image (thresholds 0.3 / 0.7); ProposalTarget = the same on
+    2,000 proposals per image with class labels and weights [10,10,5,5] (thresholds 0.5 / 0.5).  One launch
+    each; bytes are SURVEY 8d's algorithmic figures, pairs are N*M IoU evaluations (17 flop each)."""
+    ops = path.ops
+    g = torch.Generator().manual_seed(3)
+    B, M, P = 16, 100, POST_NMS
+    w, h = torch.rand(B, M, generator=g) * 240 + 16, torch.rand(B, M, generator=g) * 240 + 16
+    x1, y1 = torch.rand(B, M, generator=g) * (IMG_W - w), torch.rand(B, M, generator=g) * (IMG_H - h)
+    gt = torch.stack([x1, y1, x1 + w, y1 + h], 2).to(dev)
+    labels = torch.randint(1, 21, (B, M), generator=g).float().to(dev)
+    feat = torch.empty((B, 1, FH, FW), device=dev)
+    anchors = path.anchors(B, feat)
+    rng = np.random.default_rng(5)
+    cx, cy = rng.uniform(0, IMG_W, (B, P)), rng.uniform(0, IMG_H, (B, P))
+    pw, ph = 16 * 2 ** rng.uniform(0, 5, (B, P)), 16 * 2 ** rng.uniform(0, 5, (B, P))
+    props = np.stack([(cx - pw / 2).clip(0, IMG_W), (cy - ph / 2).clip(0, IMG_H), (cx + pw / 2).clip(0, IMG_W),
+                      (cy + ph / 2).clip(0, IMG_H)], 2).astype(np.float32)
+    props = torch.as_tensor(props).to(dev)
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    res = {}
+    cases = {"anchor_target_A20646_M100": (lambda: ops.iou_label_encode(anchors, gt, None, 0.3, 0.7, None, None,
+                                                                          want=("label", "argmax", "dev")),
+                                           A, A * 16 + M * 16 + A * 24),
+             "proposal_target_N2000_M100": (lambda: ops.iou_label_encode(props, gt, None, 0.5, 0.5, labels,
+                                                                           [10., 10., 5., 5.],
+                                                                           want=("label", "argmax", "dev")),
+                                            P, P * 16 + M * 16 + P * 24)}
+    for name, (fn, n, bytes_img) in cases.items():
+        ms = timed(fn)
+        pairs = B * n * M
+        res[name] = {"ms_per_batch16": ms, "us_per_img": ms * 1e3 / B, "algorithmic_bytes_per_img": bytes_img,
+                     "achieved_GBps": B * bytes_img / (ms * 1e-3) / 1e9,
+                     "hbm_frac": B * bytes_img / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "pairs_per_s": pairs / (ms * 1e-3),
+                     "fp32_valu_frac": pairs * 17 / (ms * 1e-3) / 157e12}
+    return {"training_targets_config3": res}
+
+
+def config5_inputs(B, dev, seed=7):
+    """800x1344, levels 13x21 .. 100x168 (A = 200,907), C = 256, tie-free logits,
+    proposal-realistic deltas under the reference decode."""
+    from objectdetection_amd.RPN.anchor_generator import AnchorGenerator
+    Himg, Wimg, C5 = 800, 1344, 256
+    fsz = [(13, 21), (25, 42), (50, 84), (100, 168)]
+    g = torch.Generator().manual_seed(seed)
+    A5 = sum(h * w for h, w in fsz) * NA
+    perm = (torch.stack([torch.randperm(A5, generator=g) for _ in range(B)]).float() / A5 - 0.5) * 8
+    cls, reg, feats, off = [], [], [], 0
+    for h, w in fsz:
+        n = h * w * NA
+        cls.append(perm[:, off:off + n].reshape(B, h, w, NA).permute(0, 3, 1, 2).contiguous().to(dev))
+        off += n
+        feats.append(torch.randn(B, C5, h, w, generator=g).to(dev))
+    anchors = torch.cat([a[0].reshape(-1, 4) for a in AnchorGenerator()((B, Himg, Wimg), feats)], 0)
+    wa, ha = (anchors[:, 2] - anchors[:, 0]).cpu(), (anchors[:, 3] - anchors[:, 1]).cpu()
+    off = 0
+    for h, w in fsz:
+        n = h * w * NA
+        cx, cy = torch.rand(B, n, generator=g) * Wimg, torch.rand(B, n, generator=g) * Himg
+        # object size 16 .. 724 px, aspect ratio 1:3 .. 3:1
+        size = 16 * 2 ** (torch.rand(B, n, generator=g) * 5.5)
+        ratio = 2 ** ((torch.rand(B, n, generator=g) * 2 - 1) * 1.585)
+        wt, ht = size * ratio.sqrt(), size / ratio.sqrt()
+        w_, h_ = wa[off:off + n], ha[off:off + n]
+        d = torch.stack([(cx - w_ / 2) / w_, (cy - h_ / 2) / h_, torch.log(wt / w_), torch.log(ht / h_)], 2)
+        reg.append(d.reshape(B, h, w, 4 * NA).permute(0, 3, 1, 2).contiguous().to(dev))
+        off += n
+    return dict(cls=cls, reg=reg, feats=feats, anchors=anchors, Himg=Himg, Wimg=Wimg, A=A5, C=C5, fsz=fsz)
+
+
+def config5_microbench(dev, B=16, reps=5):
+    """The whole path at SURVEY 8d config 5 (k = 30,000, P = 2,000, four-level MultiScaleRoIAlign), one
+    stream; a parity-test configuration reported beside the headline, not the metric."""
+    from objectdetection_amd import ops
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    x = config5_inputs(B, dev)
+    pool = ROIPooling(['1', '2', '3', '4'], [7, 7], 2)
+    fd = {str(i + 1): f for i, f in enumerate(x["feats"][::-1])}  # fine to coarse
+
+    def step(ev):
+        def mark(n):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            ev.append((n, e))
+        mark("start")
+        scores, deltas = ops.rpn_flatten(x["cls"], x["reg"])
+        mark("flatten")
+        tv, ti = ops.topk_desc(scores, 30000)
+        mark("topk")
+        boxes, _, _, count = ops.decode_clip_filter(x["anchors"], deltas, ti, tv, x["Himg"], x["Wimg"], 1e-3)
+        mark("decode_clip_filter")
+        keep, nk = ops.nms_sorted(boxes, count, 0.7, 2000)
+        mark("nms")
+        props = ops.gather_boxes(boxes, keep, nk)
+        mark("gather")
+        out, total = pool.forward_padded(fd, props, nk, [(x["Himg"], x["Wimg"])])
+        mark("roi_align")
+        return nk, total
+
+    for _ in range(2):
+        step([])
+    acc = {}
+    for _ in range(reps):
+        ev = []
+        nk, total = step(ev)
+        torch.cuda.synchronize()
+        for (_, e0), (b, e1) in zip(ev[:-1], ev[1:]):
+            acc.setdefault(b, []).append(e0.elapsed_time(e1))
+    stage = {k: float(np.mean(v)) for k, v in acc.items()}
+    ms = sum(stage.values())
+    out_bytes = int(total) * x["C"] * 49 * 4
+    return {"config5_A200907_k30000_C256": {
+        "batch": B, "ms_per_step": ms, "images_per_s": B / (ms * 1e-3), "stage_ms": stage,
+        "rois_per_step": int(total), "keeps_per_img_mean": float(nk.float().mean()),
+        "roi_align_write_GBps": out_bytes / (stage["roi_align"] * 1e-3) / 1e9,
+        "roi_align_hbm_frac": out_bytes / (stage["roi_align"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
 
 
 def nms_microbench(path, dev):

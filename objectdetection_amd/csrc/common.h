@@ -112,6 +112,12 @@ __device__ __forceinline__ uint32_t frcnn_score_key(float s)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// The score a key was made from (bit-exact, except that every NaN comes back as one quiet NaN).
+__device__ __forceinline__ float frcnn_key_score(uint32_t key)
+{
+    return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+}
+
 // Exclusive prefix count of `flag` over a 1024-thread (16-wave) block; returns the block total
 // through *total.  `wave_sums` is 16 ints of LDS.  Two barriers.
 __device__ __forceinline__ int frcnn_block_excl_count(bool flag, int *wave_sums, int *total)

@@ -131,6 +131,20 @@ __device__ __forceinline__ Sample make_sample(float y, float x, int H, int W)
     return s;
 }
 
+// One bilinear sample from a plane in global memory.  The low / high taps of a row are neighbours,
+// so each row is ONE 8-byte load (the kernels that gather through L1 are bound by the number of
+// tap loads); at the right edge, where both taps are the last pixel, the pair starts one pixel
+// earlier.  Same four products, same order of additions as the scalar form.  Needs W >= 2.
+__device__ __forceinline__ float sample_value(const float *__restrict__ f, const Sample &s)
+{
+    const int cl = (s.p2 == s.p1 && s.p1 > 0) ? 1 : 0;
+    float2 r0, r1;
+    __builtin_memcpy(&r0, f + (s.p1 - cl), 8);
+    __builtin_memcpy(&r1, f + (s.p3 - cl), 8);
+    const float v1 = cl ? r0.y : r0.x, v3 = cl ? r1.y : r1.x;
+    return s.w1 * v1 + s.w2 * r0.y + s.w3 * v3 + s.w4 * r1.y;
+}
+
 #define RA_MAX_SAMPLES 1024 // pooled_h*pooled_w*grid_h*grid_w staged per RoI in LDS (32 KB)
 #define RA_CHUNK 32         // channels per block
 
@@ -395,7 +409,7 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
 {
     extern __shared__ float4 s_plane[];
     __shared__ float4 s_rec[RAP_SEG]; // per RoI: start_w, start_h, bin_w, bin_h (feature pixels)
-    __shared__ int s_lvl[RAP_SEG];    // per RoI: pyramid level that pools it, -1 = none
+    __shared__ signed char s_lvl[RAP_SEG]; // per RoI: pyramid level that pools it, -1 = none
     __shared__ int s_off, s_cnt;
     const int b = blockIdx.z;
     const int B = gridDim.z;
@@ -476,7 +490,7 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
             roi_w = roi_w > 1.0f ? roi_w : 1.0f;
             roi_h = roi_h > 1.0f ? roi_h : 1.0f;
             s_rec[i] = make_float4(start_w, start_h, roi_w / 7.0f, roi_h / 7.0f);
-            s_lvl[i] = lv;
+            s_lvl[i] = (signed char)lv;
         }
         __syncthreads();
         // item = (RoI, bin): its tap addresses and weights are computed once and reused for every
@@ -537,8 +551,14 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
 // axis; the rare larger ones are left to the direct kernel, which is then launched with the same test
 // inverted.  Workgroup = (16-channel chunk, window, image); a window no RoI of the image falls into
 // costs one pass over the boxes and no staging.
-#define RAW_WIN 48
-#define RAW_STEP 16
+#ifndef RAW_WIN
+#define RAW_WIN 64
+#define RAW_STEP 32
+#define RAW_G 2 // float4 channel groups per workgroup: RAW_WIN^2 * 16 B * RAW_G of LDS
+#endif
+#ifndef RAW_WG_TARGET
+#define RAW_WG_TARGET 1024
+#endif
 
 struct RoiWindow {
     int win;   // iy * nwx + ix
@@ -580,6 +600,9 @@ __device__ __forceinline__ void taps_to_window(AxisTaps &t, int n_taps, int orig
         if (i < n_taps) t.idx[i] = min(max(t.idx[i] - origin, 0), RAW_WIN - 1);
 }
 
+#define RAW_LIST 1024 // RoIs of one window gathered before its chunks are staged
+#define RAW_SCAN 512  // boxes examined between two looks at the list's fill
+
 template <int GT>
 __global__ void __launch_bounds__(RAP_THREADS)
 roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
@@ -588,14 +611,12 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
                         float *__restrict__ out, int32_t *__restrict__ total_out)
 {
     extern __shared__ float4 s_plane[];
-    __shared__ float4 s_rec[RAP_SEG];
-    __shared__ int s_idx[RAP_SEG];
+    __shared__ float4 s_rec[RAW_LIST];
+    __shared__ int s_idx[RAW_LIST];
     __shared__ int s_off, s_cnt, s_n;
     const int b = blockIdx.z;
     const int B = gridDim.z;
-    const int c0 = blockIdx.x * 16;
-    const int nc = min(16, C - c0);
-    const int G = GT ? GT : (nc + 3) >> 2;
+    const int chunks = (C + 4 * RAW_G - 1) / (4 * RAW_G);
     const int HW = H * W;
     const int wid = blockIdx.y;
     const int wy0 = (wid / nwx) * RAW_STEP, wx0 = (wid % nwx) * RAW_STEP;
@@ -609,62 +630,21 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
             tot += c;
         }
         s_off = off;
+        s_n = 0;
         if (total_out && blockIdx.x == 0 && blockIdx.y == 0 && b == 0) *total_out = tot;
     }
     __syncthreads();
     const int cnt = s_cnt;
     const float4 *pb = props + (long long)b * P;
-    // does any RoI of the image belong here?  (decides whether the window is staged at all)
-    int mine = 0;
-    for (int i = threadIdx.x; i < cnt; i += RAP_THREADS) {
-        const float4 box = pb[i];
-        int lv = 0;
-        if (n_levels > 1) lv = map_level(box, k_min, k_max);
-        const RoiWindow rw = roi_window(roi_record(box, scale), H, W, nwy, nwx);
-        mine |= (lv == level && rw.fits && rw.win == wid) ? 1 : 0;
-    }
-    if (!__syncthreads_or(mine)) return;
-    // stage the window: rows wy0.. and columns wx0.. that exist in the plane
     const int wh = min(RAW_WIN, H - wy0), ww = min(RAW_WIN, W - wx0);
-    const float *fb = feat + ((long long)b * C + c0) * HW;
     const int per_g = wh * ww;
-    for (int t0 = threadIdx.x; t0 < G * per_g; t0 += 4 * RAP_THREADS) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u * RAP_THREADS;
-            v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (t < G * per_g) {
-                const int g = t / per_g;
-                const int p = t - g * per_g;
-                const int ly = p / ww, lx = p - ly * ww;
-                const float *f = fb + (long long)(4 * g) * HW + (long long)(wy0 + ly) * W + wx0 + lx;
-                v[u].x = f[0];
-                if (4 * g + 1 < nc) v[u].y = f[HW];
-                if (4 * g + 2 < nc) v[u].z = f[2 * HW];
-                if (4 * g + 3 < nc) v[u].w = f[3 * HW];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u * RAP_THREADS;
-            if (t < G * per_g) {
-                const int g = t / per_g;
-                const int p = t - g * per_g;
-                const int ly = p / ww, lx = p - ly * ww;
-                s_plane[(ly * G + g) * RAW_WIN + (lx ^ rap_swz(ly))] = v[u];
-            }
-        }
-    }
-    const int row_stride = G * RAW_WIN;
-    float *ob = out + ((long long)s_off * C + c0) * 49;
     const int bin = threadIdx.x & 63;
     const int ph = bin / 7, pw = bin - ph * 7;
-    for (int seg = 0; seg < cnt; seg += RAP_SEG) {
-        const int nseg = min(RAP_SEG, cnt - seg);
-        __syncthreads(); // staging done / readers of the previous segment's list are done
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
+    // The boxes are examined ONCE per workgroup: the window's RoIs collect in a list, and the list is
+    // worked off for every channel chunk of this workgroup (blockIdx.x, + gridDim.x, ...) before it
+    // can overflow.  A window no RoI of the image falls into costs that one pass and no staging.
+    for (int seg = 0; seg < cnt; seg += RAW_SCAN) {
+        const int nseg = min(RAW_SCAN, cnt - seg);
         for (int i = threadIdx.x; i < nseg; i += RAP_THREADS) {
             const float4 box = pb[seg + i];
             int lv = 0;
@@ -679,35 +659,78 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
         }
         __syncthreads();
         const int n_list = s_n;
-        // one whole RoI per wave iteration, lane = bin (see roi_align_plane_kernel)
-        for (int e = (int)(threadIdx.x >> 6); e < (bin < 49 ? n_list : 0); e += RAP_THREADS / 64) {
-            const float4 rec = s_rec[e];
-            float *o = ob + (long long)s_idx[e] * C * 49 + bin;
-            const float start_w = rec.x, start_h = rec.y, bin_w = rec.z, bin_h = rec.w;
-            AxisSample ys[2], xs[2];
+        __syncthreads(); // everyone has read the fill before the next scan adds to it
+        if (n_list <= RAW_LIST - RAW_SCAN && seg + RAW_SCAN < cnt) continue; // room for another scan
+        for (int ch = blockIdx.x; ch < (n_list ? chunks : 0); ch += gridDim.x) {
+            const int c0 = ch * (4 * RAW_G);
+            const int nc = min(4 * RAW_G, C - c0);
+            const int G = GT ? GT : (nc + 3) >> 2;
+            const float *fb = feat + ((long long)b * C + c0) * HW;
+            __syncthreads(); // the previous chunk's readers are done with the window
+            for (int t0 = threadIdx.x; t0 < G * per_g; t0 += 4 * RAP_THREADS) {
+                float4 v[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
-                xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * RAP_THREADS;
+                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (t < G * per_g) {
+                        const int g = t / per_g;
+                        const int p = t - g * per_g;
+                        const int ly = p / ww, lx = p - ly * ww;
+                        const float *f = fb + (long long)(4 * g) * HW + (long long)(wy0 + ly) * W + wx0 + lx;
+                        v[u].x = f[0];
+                        if (4 * g + 1 < nc) v[u].y = f[HW];
+                        if (4 * g + 2 < nc) v[u].z = f[2 * HW];
+                        if (4 * g + 3 < nc) v[u].w = f[3 * HW];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u * RAP_THREADS;
+                    if (t < G * per_g) {
+                        const int g = t / per_g;
+                        const int p = t - g * per_g;
+                        const int ly = p / ww, lx = p - ly * ww;
+                        s_plane[(ly * G + g) * RAW_WIN + (lx ^ rap_swz(ly))] = v[u];
+                    }
+                }
             }
-            const bool y3 = __all(axis_mergeable(ys[0], ys[1]));
-            const bool x3 = __all(axis_mergeable(xs[0], xs[1]));
-            AxisTaps ty = y3 ? axis_taps3(ys[0], ys[1], 0.25f, H) : axis_taps4(ys[0], ys[1], 0.25f);
-            AxisTaps tx = x3 ? axis_taps3(xs[0], xs[1], 1.0f, W) : axis_taps4(xs[0], xs[1], 1.0f);
-            taps_to_window(ty, y3 ? 3 : 4, wy0);
-            taps_to_window(tx, x3 ? 3 : 4, wx0);
-            if (y3) {
-                if (x3)
-                    rap_item<3, 3, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
-                else
-                    rap_item<3, 4, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
-            } else {
-                if (x3)
-                    rap_item<4, 3, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
-                else
-                    rap_item<4, 4, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+            __syncthreads();
+            const int row_stride = G * RAW_WIN;
+            float *ob = out + ((long long)s_off * C + c0) * 49;
+            // one whole RoI per wave iteration, lane = bin (see roi_align_plane_kernel)
+            for (int e = (int)(threadIdx.x >> 6); e < (bin < 49 ? n_list : 0); e += RAP_THREADS / 64) {
+                const float4 rec = s_rec[e];
+                float *o = ob + (long long)s_idx[e] * C * 49 + bin;
+                const float start_w = rec.x, start_h = rec.y, bin_w = rec.z, bin_h = rec.w;
+                AxisSample ys[2], xs[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ys[i] = axis_sample(start_h + (float)ph * bin_h + ((float)i + 0.5f) * bin_h / 2.0f, H);
+                    xs[i] = axis_sample(start_w + (float)pw * bin_w + ((float)i + 0.5f) * bin_w / 2.0f, W);
+                }
+                const bool y3 = __all(axis_mergeable(ys[0], ys[1]));
+                const bool x3 = __all(axis_mergeable(xs[0], xs[1]));
+                AxisTaps ty = y3 ? axis_taps3(ys[0], ys[1], 0.25f, H) : axis_taps4(ys[0], ys[1], 0.25f);
+                AxisTaps tx = x3 ? axis_taps3(xs[0], xs[1], 1.0f, W) : axis_taps4(xs[0], xs[1], 1.0f);
+                taps_to_window(ty, y3 ? 3 : 4, wy0);
+                taps_to_window(tx, x3 ? 3 : 4, wx0);
+                if (y3) {
+                    if (x3)
+                        rap_item<3, 3, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+                    else
+                        rap_item<3, 4, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+                } else {
+                    if (x3)
+                        rap_item<4, 3, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+                    else
+                        rap_item<4, 4, GT>(s_plane, RAW_WIN, row_stride, G, nc, ty, tx, o);
+                }
             }
         }
+        __syncthreads(); // every reader of the list is done
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
     }
 }
 
@@ -721,7 +744,8 @@ roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, in
                                 float *__restrict__ out, int32_t *__restrict__ total_out)
 {
     __shared__ Sample s_samp[RA_MAX_SAMPLES];
-    __shared__ int s_off, s_cnt;
+    __shared__ int s_list[256];
+    __shared__ int s_off, s_cnt, s_nl;
     const int b = blockIdx.z;
     const int B = gridDim.z;
     if (threadIdx.x == 0) {
@@ -744,50 +768,79 @@ roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, in
     const int c0 = blockIdx.y * RA_CHUNK;
     const int nc = min(RA_CHUNK, C - c0);
     const float *fb = feat + ((long long)b * C + c0) * H * W;
-    for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
-        float4 box = props[(long long)b * P + j];
-        float *ob = out + ((long long)(s_off + j) * C + c0) * bins;
-        if (n_levels > 1) {
-            int lv = map_level(box, k_min, k_max);
-            bool none = lv < 0 || lv >= n_levels;
-            if (none && level == 0)
-                for (int t = threadIdx.x; t < nc * bins; t += blockDim.x) ob[t] = 0.0f;
-            if (lv != level) continue;
-        }
-        // behind the window kernel (nwy > 0): only the RoIs that fit no window are left to do
-        if (nwy > 0 && roi_window(roi_record(box, scale), H, W, nwy, nwx).fits) continue;
-        float start_w = box.x * scale, start_h = box.y * scale;
-        float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
-        roi_w = roi_w > 1.0f ? roi_w : 1.0f;
-        roi_h = roi_h > 1.0f ? roi_h : 1.0f;
-        float bin_h = roi_h / (float)pooled_h, bin_w = roi_w / (float)pooled_w;
-        __syncthreads(); // previous RoI's readers are done with s_samp
-        for (int t = threadIdx.x; t < nsamp; t += blockDim.x) {
-            int bin = t / per_bin;
-            int si = t - bin * per_bin;
-            int iy = si / sampling_ratio, ix = si - iy * sampling_ratio;
-            int ph = bin / pooled_w, pw = bin - ph * pooled_w;
-            float yy = start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)sampling_ratio;
-            float xx = start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)sampling_ratio;
-            s_samp[t] = make_sample(yy, xx, H, W);
+    // Which of this workgroup's RoIs (blockIdx.x, + gridDim.x, ...) need work is decided by all threads
+    // at once -- one box per thread, one memory latency -- instead of one box after the other.
+    for (int base = 0; base < cnt; base += gridDim.x * blockDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_nl = 0;
+        __syncthreads();
+        {
+            const int j = base + blockIdx.x + gridDim.x * threadIdx.x;
+            int code = -1;
+            if (j < cnt) {
+                const float4 box = props[(long long)b * P + j];
+                bool todo = true, zero = false;
+                if (n_levels > 1) {
+                    const int lv = map_level(box, k_min, k_max);
+                    zero = (lv < 0 || lv >= n_levels) && level == 0; // no level pools it: zeros, written once
+                    todo = zero || lv == level;
+                }
+                // behind the window kernel (nwy > 0): only the RoIs that fit no window are left to do
+                if (todo && !zero && nwy > 0 && roi_window(roi_record(box, scale), H, W, nwy, nwx).fits) todo = false;
+                if (todo) code = zero ? (j | 0x40000000) : j;
+            }
+            if (code >= 0) s_list[atomicAdd(&s_nl, 1)] = code;
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < nc * bins; t += blockDim.x) {
-            int c = t / bins;
-            int bin = t - c * bins;
-            const float *f = fb + (long long)c * H * W;
-            float acc = 0.0f;
-            const Sample *sp = s_samp + bin * per_bin;
-            for (int si = 0; si < per_bin; ++si) {
-                Sample s = sp[si];
-                acc += s.w1 * f[s.p1] + s.w2 * f[s.p2] + s.w3 * f[s.p3] + s.w4 * f[s.p4];
+        const int n_list = s_nl;
+        for (int e = 0; e < n_list; ++e) {
+            const int code = s_list[e];
+            const int j = code & 0x3FFFFFFF;
+            float4 box = props[(long long)b * P + j];
+            float *ob = out + ((long long)(s_off + j) * C + c0) * bins;
+            if (code & 0x40000000) {
+                for (int t = threadIdx.x; t < nc * bins; t += blockDim.x) ob[t] = 0.0f;
+                continue;
             }
-            ob[t] = acc / (float)per_bin;
+            float start_w = box.x * scale, start_h = box.y * scale;
+            float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
+            roi_w = roi_w > 1.0f ? roi_w : 1.0f;
+            roi_h = roi_h > 1.0f ? roi_h : 1.0f;
+            float bin_h = roi_h / (float)pooled_h, bin_w = roi_w / (float)pooled_w;
+            __syncthreads(); // previous RoI's readers are done with s_samp
+            for (int t = threadIdx.x; t < nsamp; t += blockDim.x) {
+                int bin = t / per_bin;
+                int si = t - bin * per_bin;
+                int iy = si / sampling_ratio, ix = si - iy * sampling_ratio;
+                int ph = bin / pooled_w, pw = bin - ph * pooled_w;
+                float yy = start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)sampling_ratio;
+                float xx = start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)sampling_ratio;
+                s_samp[t] = make_sample(yy, xx, H, W);
+            }
+            __syncthreads();
+#pragma unroll 3
+            for (int t = threadIdx.x; t < nc * bins; t += blockDim.x) {
+                int c = t / bins;
+                int bin = t - c * bins;
+                const float *f = fb + (long long)c * H * W;
+                float acc = 0.0f;
+                const Sample *sp = s_samp + bin * per_bin;
+                if (W >= 2) {
+#pragma unroll 4
+                    for (int si = 0; si < per_bin; ++si) acc += sample_value(f, sp[si]);
+                } else {
+                    for (int si = 0; si < per_bin; ++si) {
+                        Sample s = sp[si];
+                        acc += s.w1 * f[s.p1] + s.w2 * f[s.p2] + s.w3 * f[s.p3] + s.w4 * f[s.p4];
+                    }
+                }
+                ob[t] = acc / (float)per_bin;
+            }
         }
     }
 }
 
-#define RAP_LDS_BUDGET (148 * 1024) // dynamic part; 10.3 KB of static LDS (RoI records) on top
+#define RAP_LDS_BUDGET (150 * 1024) // dynamic part (8 channels of a 50 x 96 plane); 8.7 KB of static LDS on top
 
 extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W,
                                            const float *props, const int32_t *count, int P,
@@ -857,21 +910,25 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         if ((long long)nwy * nwx > 65535) {
             nwy = nwx = 0;
         } else {
-            const int chunks16 = (C + 15) / 16;
-            const size_t lds = (size_t)RAW_WIN * RAW_WIN * 64;
-            const bool full = C % 16 == 0;
+            // a workgroup examines the image's boxes once and then works through several channel chunks
+            // of its window; as many channel splits as give the chip about four workgroups per CU
+            const int chunks = (C + 4 * RAW_G - 1) / (4 * RAW_G);
+            int chunks16 = (RAW_WG_TARGET + nwy * nwx * B - 1) / (nwy * nwx * B);
+            chunks16 = chunks16 < 1 ? 1 : (chunks16 > chunks ? chunks : chunks16);
+            const size_t lds = (size_t)RAW_WIN * RAW_WIN * 16 * RAW_G;
+            const bool full = C % (4 * RAW_G) == 0;
             static bool configured4 = false, configured0 = false;
             bool &configured = full ? configured4 : configured0;
             if (!configured) {
                 hipError_t e = hipFuncSetAttribute(
-                    full ? (const void *)roi_align_window_kernel<4> : (const void *)roi_align_window_kernel<0>,
+                    full ? (const void *)roi_align_window_kernel<RAW_G> : (const void *)roi_align_window_kernel<0>,
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
                               hipGetErrorString(e));
                 configured = true;
             }
             if (full)
-                hipLaunchKernelGGL((roi_align_window_kernel<4>), dim3(chunks16, nwy * nwx, B), dim3(RAP_THREADS), lds,
+                hipLaunchKernelGGL((roi_align_window_kernel<RAW_G>), dim3(chunks16, nwy * nwx, B), dim3(RAP_THREADS), lds,
                                    (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P,
                                    spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, out, total_out);
             else

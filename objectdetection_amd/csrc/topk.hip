@@ -648,7 +648,7 @@ topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restri
                     if (pass == 2) {
                         if (pos < (unsigned)k) {
                             idx_out[(long long)b * k + pos] = (int32_t)idx;
-                            if (val_out) val_out[(long long)b * k + pos] = sc[idx];
+                            if (val_out) val_out[(long long)b * k + pos] = frcnn_key_score(kreg[r]);
                         }
                     } else {
                         kout[pos] = kreg[r];
