@@ -600,6 +600,46 @@ __device__ __forceinline__ void taps_to_window(AxisTaps &t, int n_taps, int orig
         if (i < n_taps) t.idx[i] = min(max(t.idx[i] - origin, 0), RAW_WIN - 1);
 }
 
+// Staging of a window: thread t owns pixel column t % RAW_WIN of rows t / RAW_WIN + 16 k, for every
+// channel group -- offsets between a thread's slots are compile-time multiples of the plane and row
+// strides, and the LDS swizzle (low four bits of the row) is the same for all of them.
+#define RAW_ROWS (RAP_THREADS / RAW_WIN)           // rows per pass of the workgroup
+#define RAW_PASSES (RAW_WIN / RAW_ROWS)            // passes per channel group
+#define RAW_SLOTS (RAW_G * RAW_PASSES)             // float4 registers per thread
+static_assert(RAP_THREADS % RAW_WIN == 0 && RAW_WIN % RAW_ROWS == 0 && RAW_ROWS % 16 == 0, "window staging layout");
+
+__device__ __forceinline__ void raw_fetch(float4 (&v)[RAW_SLOTS], const float *__restrict__ feat, int b, int C,
+                                          int HW, int W, int ch, int wy0, int wx0, int wh, int ww)
+{
+    const int c0 = ch * (4 * RAW_G);
+    const int nc = min(4 * RAW_G, C - c0);
+    const int lx = threadIdx.x % RAW_WIN, ly0 = threadIdx.x / RAW_WIN;
+    const float *f0 = feat + ((long long)b * C + c0) * HW + (long long)(wy0 + ly0) * W + wx0 + lx;
+#pragma unroll
+    for (int u = 0; u < RAW_SLOTS; ++u) {
+        const int g = u / RAW_PASSES, k = u % RAW_PASSES;
+        v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (lx < ww && ly0 + RAW_ROWS * k < wh && 4 * g < nc) {
+            const float *f = f0 + (long long)(4 * g) * HW + (long long)(RAW_ROWS * k) * W;
+            v[u].x = f[0];
+            if (4 * g + 1 < nc) v[u].y = f[HW];
+            if (4 * g + 2 < nc) v[u].z = f[2 * HW];
+            if (4 * g + 3 < nc) v[u].w = f[3 * HW];
+        }
+    }
+}
+
+__device__ __forceinline__ void raw_store(float4 *s_plane, const float4 (&v)[RAW_SLOTS], int G, int wh, int ww)
+{
+    const int lx = threadIdx.x % RAW_WIN, ly0 = threadIdx.x / RAW_WIN;
+    const int col = lx ^ rap_swz(ly0); // rows RAW_ROWS apart share their low four bits
+#pragma unroll
+    for (int u = 0; u < RAW_SLOTS; ++u) {
+        const int g = u / RAW_PASSES, ly = ly0 + RAW_ROWS * (u % RAW_PASSES);
+        if (lx < ww && ly < wh && g < G) s_plane[(ly * G + g) * RAW_WIN + col] = v[u];
+    }
+}
+
 #define RAW_LIST 1024 // RoIs of one window gathered before its chunks are staged
 #define RAW_SCAN 512  // boxes examined between two looks at the list's fill
 
@@ -637,7 +677,6 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
     const int cnt = s_cnt;
     const float4 *pb = props + (long long)b * P;
     const int wh = min(RAW_WIN, H - wy0), ww = min(RAW_WIN, W - wx0);
-    const int per_g = wh * ww;
     const int bin = threadIdx.x & 63;
     const int ph = bin / 7, pw = bin - ph * 7;
     // The boxes are examined ONCE per workgroup: the window's RoIs collect in a list, and the list is
@@ -665,35 +704,13 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
             const int c0 = ch * (4 * RAW_G);
             const int nc = min(4 * RAW_G, C - c0);
             const int G = GT ? GT : (nc + 3) >> 2;
-            const float *fb = feat + ((long long)b * C + c0) * HW;
             __syncthreads(); // the previous chunk's readers are done with the window
-            for (int t0 = threadIdx.x; t0 < G * per_g; t0 += 4 * RAP_THREADS) {
-                float4 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + u * RAP_THREADS;
-                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (t < G * per_g) {
-                        const int g = t / per_g;
-                        const int p = t - g * per_g;
-                        const int ly = p / ww, lx = p - ly * ww;
-                        const float *f = fb + (long long)(4 * g) * HW + (long long)(wy0 + ly) * W + wx0 + lx;
-                        v[u].x = f[0];
-                        if (4 * g + 1 < nc) v[u].y = f[HW];
-                        if (4 * g + 2 < nc) v[u].z = f[2 * HW];
-                        if (4 * g + 3 < nc) v[u].w = f[3 * HW];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int t = t0 + u * RAP_THREADS;
-                    if (t < G * per_g) {
-                        const int g = t / per_g;
-                        const int p = t - g * per_g;
-                        const int ly = p / ww, lx = p - ly * ww;
-                        s_plane[(ly * G + g) * RAW_WIN + (lx ^ rap_swz(ly))] = v[u];
-                    }
-                }
+            {
+                // (fetching the next chunk's window into registers while this one's items run was tried:
+                // the item code needs the registers, the fetched window spilled, 0.67 -> 0.88 ms)
+                float4 v[RAW_SLOTS];
+                raw_fetch(v, feat, b, C, HW, W, ch, wy0, wx0, wh, ww);
+                raw_store(s_plane, v, G, wh, ww);
             }
             __syncthreads();
             const int row_stride = G * RAW_WIN;
