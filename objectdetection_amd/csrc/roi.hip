@@ -405,15 +405,23 @@ __global__ void __launch_bounds__(RAP_THREADS)
 roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
                        const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
                        int CC, float scale, int level, int n_levels, int k_min, int k_max,
-                       float *__restrict__ out, int32_t *__restrict__ total_out)
+                       int chunks, int splits, int B, float *__restrict__ out, int32_t *__restrict__ total_out)
 {
     extern __shared__ float4 s_plane[];
     __shared__ float4 s_rec[RAP_SEG]; // per RoI: start_w, start_h, bin_w, bin_h (feature pixels)
     __shared__ signed char s_lvl[RAP_SEG]; // per RoI: pyramid level that pools it, -1 = none
     __shared__ int s_off, s_cnt;
-    const int b = blockIdx.z;
-    const int B = gridDim.z;
-    const int c0 = blockIdx.x * CC;
+    // Block order: the workgroups of all channel chunks of one (image, RoI split) sit 8 apart in the 1-D
+    // grid.  Blocks i and i + 8 are dealt to the same XCD (observed dispatch order, used for speed only),
+    // so the neighbouring 3,136-byte pieces that the chunks of a RoI row write at about the same time
+    // meet in ONE L2 and leave it as whole lines: tools/store_probe.hip, the same stores 0.73 -> 0.62 ms.
+    const int slot = blockIdx.x >> 3;
+    const int chunk = slot % chunks;
+    const int grp = (slot / chunks) * 8 + (blockIdx.x & 7); // (image, split); padded to a multiple of 8
+    if (grp >= splits * B) return;
+    const int split = grp % splits;
+    const int b = grp / splits;
+    const int c0 = chunk * CC;
     const int nc = min(CC, C - c0);
     const int G = GT ? GT : (nc + 3) >> 2;
     const int HW = H * W;
@@ -428,7 +436,7 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
             tot += c;
         }
         s_off = off;
-        if (total_out && blockIdx.x == 0 && blockIdx.y == 0 && b == 0) *total_out = tot;
+        if (total_out && chunk == 0 && grp == 0) *total_out = tot;
     }
     // stage the chunk's planes: 4 coalesced plane reads -> one 16-byte LDS write per pixel/group.
     // Four pixels per thread are fetched before any is written, so a workgroup pays about three
@@ -464,8 +472,8 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
     }
     __syncthreads();
     const int cnt = s_cnt;
-    const int per = (cnt + gridDim.y - 1) / gridDim.y;
-    const int j0 = blockIdx.y * per;
+    const int per = (cnt + splits - 1) / splits;
+    const int j0 = split * per;
     const int j1 = min(cnt, j0 + per);
     const int row_stride = G * WS;
     const float4 *pb = props + (long long)b * P;
@@ -857,6 +865,9 @@ roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, in
     }
 }
 
+#ifndef RAP_WG_TARGET
+#define RAP_WG_TARGET (4 * 256)
+#endif
 #define RAP_LDS_BUDGET (150 * 1024) // dynamic part (8 channels of a 50 x 96 plane); 8.7 KB of static LDS on top
 
 extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W,
@@ -891,7 +902,7 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         // RoI splits: about four workgroups per CU.  Fewer, longer workgroups stage fewer planes
         // (0.745 ms at 2 per CU, 0.748 at 4, 0.770 at 8, 0.838 at 16); shorter ones let the small
         // kernels of the next batch on another stream find a free CU sooner (bench.py pipelining).
-        int splits = (4 * 256 + chunks * B - 1) / (chunks * B);
+        int splits = (RAP_WG_TARGET + chunks * B - 1) / (chunks * B);
         if (splits < 1) splits = 1;
         if (splits > 16) splits = 16;
         size_t lds = (size_t)plane_bytes * (size_t)CC;
@@ -907,14 +918,17 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
                           hipGetErrorString(e));
             configured = lds;
         }
+        const long long groups8 = ((long long)splits * B + 7) / 8 * 8; // (image, split) groups, padded (see kernel)
+        FRCNN_REQUIRE(groups8 * chunks < (1ll << 31), "roi_align_batched: grid too large");
+        const dim3 grid((unsigned)(groups8 * chunks));
         if (full)
-            hipLaunchKernelGGL((roi_align_plane_kernel<4, 64>), dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
+            hipLaunchKernelGGL((roi_align_plane_kernel<4, 64>), grid, dim3(RAP_THREADS), lds,
                                (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
-                               spatial_scale, level, n_levels, k_min, k_max, out, total_out);
+                               spatial_scale, level, n_levels, k_min, k_max, chunks, splits, B, out, total_out);
         else
-            hipLaunchKernelGGL((roi_align_plane_kernel<0, 0>), dim3(chunks, splits, B), dim3(RAP_THREADS), lds,
+            hipLaunchKernelGGL((roi_align_plane_kernel<0, 0>), grid, dim3(RAP_THREADS), lds,
                                (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
-                               spatial_scale, level, n_levels, k_min, k_max, out, total_out);
+                               spatial_scale, level, n_levels, k_min, k_max, chunks, splits, B, out, total_out);
         FRCNN_CHECK_LAUNCH("roi_align_plane");
         return FRCNN_OK;
     }

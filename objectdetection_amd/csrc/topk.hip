@@ -15,7 +15,9 @@
 // cls (B,na,h,w) -> scores[b, off + cell*na + a]; reg (B,4na,h,w) -> deltas[b, off + cell*na + a].
 // A block handles 64 cells: NCHW reads are coalesced along the cell index (x fastest), the
 // transposed writes go through LDS so that they are coalesced along (cell, a).
+#ifndef FLAT_CELLS
 #define FLAT_CELLS 64
+#endif
 
 __global__ void __launch_bounds__(256)
 rpn_flatten_kernel(const float *__restrict__ cls, const float *__restrict__ reg, int na, int hw,

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(1024) shape_kernel(float *out, int P, int C)
             out[(((long long)b * P + j0 + jl) * C + chunk * 16) * 49 + e] = (float)e;
         }
     } else {
-        for (int jl = wave; jl < j1 - j0; jl += 16) { // one RoI per wave iteration
+        for (int jl = wave; jl < j1 - j0; jl += (int)(blockDim.x >> 6)) { // one RoI per wave iteration
             float *o = out + (((long long)b * P + j0 + jl) * C + chunk * 16) * 49;
             if (lane < 49) {
                 if (SHAPE == 1) {
@@ -152,6 +152,38 @@ __global__ void __launch_bounds__(1024) shape_kernel(float *out, int P, int C)
                         if (SHAPE == 3) __builtin_nontemporal_store(v, (f4 *)o + g * 49 + lane);
                         else ((f4 *)o)[g * 49 + lane] = v;
                     }
+                }
+            }
+        }
+    }
+}
+
+// modes 29-31: shape_kernel's per-wave pieces with the XCD-grouped block order of mode 12.
+template <int SHAPE>
+__global__ void __launch_bounds__(1024) shape_xcd_kernel(float *out, int P, int C, int splits)
+{
+    const int cpr = C / 16;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int chunk = slot % cpr;
+    const int grp = (slot / cpr) * 8 + xcd;
+    const int split = grp % splits, b = grp / splits;
+    const int per = (P + splits - 1) / splits;
+    const int j0 = split * per, j1 = min(P, j0 + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int jl = wave; jl < j1 - j0; jl += (int)(blockDim.x >> 6)) {
+        float *o = out + (((long long)b * P + j0 + jl) * C + chunk * 16) * 49;
+        if (lane < 49) {
+            if (SHAPE == 1) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) o[c * 49 + lane] = (float)c;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f4 v = {1.0f, (float)g, 3.0f, 4.0f};
+                    if (SHAPE == 3) __builtin_nontemporal_store(v, (f4 *)o + g * 49 + lane);
+                    else ((f4 *)o)[g * 49 + lane] = v;
                 }
             }
         }
@@ -206,7 +238,7 @@ int main()
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const int reps = 10;
-    for (int mode = 0; mode < 26; ++mode) {
+    for (int mode = 0; mode < 35; ++mode) {
         float ms = 0;
         for (int r = -2; r < reps; ++r) {
             if (r == 0) CHECK(hipEventRecord(e0, 0));
@@ -236,6 +268,14 @@ int main()
             case 24: hipLaunchKernelGGL(item_seq_kernel, dim3(32, 2, B), dim3(1024), 0, 0, (float *)out, P, C, 64); break;
             case 25: hipLaunchKernelGGL(item_seq_kernel, dim3(32, 2, B), dim3(1024), 0, 0, (float *)out, P, C, 4); break;
             case 11: hipLaunchKernelGGL(piece_kernel, dim3(32, 1, B), dim3(1024), 0, 0, out, P, 196, 32); break;
+            case 29: hipLaunchKernelGGL((shape_xcd_kernel<1>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
+            case 30: hipLaunchKernelGGL((shape_xcd_kernel<2>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
+            case 31: hipLaunchKernelGGL((shape_xcd_kernel<3>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
+            case 32: hipLaunchKernelGGL((shape_xcd_kernel<1>), dim3(32 * 4 * B), dim3(1024), 0, 0, (float *)out, P, C, 4); break;
+            case 33: hipLaunchKernelGGL((shape_xcd_kernel<3>), dim3(32 * 4 * B), dim3(1024), 0, 0, (float *)out, P, C, 4); break;
+            case 26: hipLaunchKernelGGL((shape_kernel<1>), dim3(32, 2, B), dim3(768), 0, 0, (float *)out, P, C); break;
+            case 27: hipLaunchKernelGGL((shape_kernel<2>), dim3(32, 2, B), dim3(768), 0, 0, (float *)out, P, C); break;
+            case 28: hipLaunchKernelGGL((shape_kernel<3>), dim3(32, 2, B), dim3(768), 0, 0, (float *)out, P, C); break;
             case 7: hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(1024), 0, 0, out, n4); break;
             }
         }
