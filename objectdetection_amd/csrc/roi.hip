@@ -397,7 +397,8 @@ __device__ __forceinline__ void rap_item(const float4 *s_plane, int WS, int row_
 // the 0.91 ms; the arithmetic alone (LDS taps + packed FMAs + per-item set-up) takes 0.66 ms and
 // overlaps with them only in part.  How the 3.2 GB are handed to the memory system matters more
 // than anything computed here: the same bytes written as 64-item slices that straddle RoIs took
-// 1.07 ms, as whole (RoI, chunk) pieces per wave 0.77 ms (tools/store_probe.hip).
+// 1.07 ms, as whole (RoI, chunk) pieces per wave 0.77 ms (tools/store_probe.hip), and with the
+// XCD-grouped block order below 0.62 ms (the kernel: 0.66 ms).
 // GT  = channel groups per chunk known at compile time (4 = a full 16-channel chunk) or 0.
 // WST = compile-time LDS row stride in pixels (64 covers W <= 64) or 0 for a runtime stride.
 template <int GT, int WST>
@@ -656,17 +657,21 @@ __global__ void __launch_bounds__(RAP_THREADS)
 roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
                         const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
                         float scale, int level, int n_levels, int k_min, int k_max, int nwy, int nwx,
-                        float *__restrict__ out, int32_t *__restrict__ total_out)
+                        int csplit, int B, float *__restrict__ out, int32_t *__restrict__ total_out)
 {
     extern __shared__ float4 s_plane[];
     __shared__ float4 s_rec[RAW_LIST];
     __shared__ int s_idx[RAW_LIST];
     __shared__ int s_off, s_cnt, s_n;
-    const int b = blockIdx.z;
-    const int B = gridDim.z;
+    // block order as in roi_align_plane_kernel: the channel splits of one (window, image) share an XCD
+    const int slot = blockIdx.x >> 3;
+    const int cs = slot % csplit;
+    const int grp = (slot / csplit) * 8 + (blockIdx.x & 7); // (window, image); padded to a multiple of 8
+    if (grp >= nwy * nwx * B) return;
+    const int wid = grp % (nwy * nwx);
+    const int b = grp / (nwy * nwx);
     const int chunks = (C + 4 * RAW_G - 1) / (4 * RAW_G);
     const int HW = H * W;
-    const int wid = blockIdx.y;
     const int wy0 = (wid / nwx) * RAW_STEP, wx0 = (wid % nwx) * RAW_STEP;
     if (threadIdx.x == 0) {
         int off = 0, tot = 0;
@@ -679,7 +684,7 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
         }
         s_off = off;
         s_n = 0;
-        if (total_out && blockIdx.x == 0 && blockIdx.y == 0 && b == 0) *total_out = tot;
+        if (total_out && cs == 0 && grp == 0) *total_out = tot;
     }
     __syncthreads();
     const int cnt = s_cnt;
@@ -688,7 +693,7 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
     const int bin = threadIdx.x & 63;
     const int ph = bin / 7, pw = bin - ph * 7;
     // The boxes are examined ONCE per workgroup: the window's RoIs collect in a list, and the list is
-    // worked off for every channel chunk of this workgroup (blockIdx.x, + gridDim.x, ...) before it
+    // worked off for every channel chunk of this workgroup (cs, + csplit, ...) before it
     // can overflow.  A window no RoI of the image falls into costs that one pass and no staging.
     for (int seg = 0; seg < cnt; seg += RAW_SCAN) {
         const int nseg = min(RAW_SCAN, cnt - seg);
@@ -708,7 +713,7 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
         const int n_list = s_n;
         __syncthreads(); // everyone has read the fill before the next scan adds to it
         if (n_list <= RAW_LIST - RAW_SCAN && seg + RAW_SCAN < cnt) continue; // room for another scan
-        for (int ch = blockIdx.x; ch < (n_list ? chunks : 0); ch += gridDim.x) {
+        for (int ch = cs; ch < (n_list ? chunks : 0); ch += csplit) {
             const int c0 = ch * (4 * RAW_G);
             const int nc = min(4 * RAW_G, C - c0);
             const int G = GT ? GT : (nc + 3) >> 2;
@@ -958,14 +963,19 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
                               hipGetErrorString(e));
                 configured = true;
             }
+            const long long groups8 = ((long long)nwy * nwx * B + 7) / 8 * 8;
+            FRCNN_REQUIRE(groups8 * chunks16 < (1ll << 31), "roi_align_batched: grid too large");
+            const dim3 grid((unsigned)(groups8 * chunks16));
             if (full)
-                hipLaunchKernelGGL((roi_align_window_kernel<RAW_G>), dim3(chunks16, nwy * nwx, B), dim3(RAP_THREADS), lds,
+                hipLaunchKernelGGL((roi_align_window_kernel<RAW_G>), grid, dim3(RAP_THREADS), lds,
                                    (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P,
-                                   spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, out, total_out);
+                                   spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, chunks16, B, out,
+                                   total_out);
             else
-                hipLaunchKernelGGL((roi_align_window_kernel<0>), dim3(chunks16, nwy * nwx, B), dim3(RAP_THREADS), lds,
+                hipLaunchKernelGGL((roi_align_window_kernel<0>), grid, dim3(RAP_THREADS), lds,
                                    (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P,
-                                   spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, out, total_out);
+                                   spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, chunks16, B, out,
+                                   total_out);
             FRCNN_CHECK_LAUNCH("roi_align_window");
         }
     }
