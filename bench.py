@@ -32,6 +32,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 IMG_H, IMG_W, FH, FW, NA, C = 600, 1000, 37, 62, 9, 512
 A = FH * FW * NA
 PRE_NMS, POST_NMS, NMS_THR, MIN_SIZE = 12000, 2000, 0.7, 1e-3
+TOPK_SLICES_PIPELINED = int(os.environ.get("BENCH_TOPK_SLICES", "1"))
 
 
 _ANCHOR_WH = None
@@ -155,7 +156,8 @@ class Path:
             mark("start", pipe.s_prop)
             scores, deltas = ops.rpn_flatten([cls], [reg])
             mark("flatten", pipe.s_prop)
-            top_val, top_idx = ops.topk_desc(scores, PRE_NMS)
+            # one workgroup per image: beside RoIAlign every slice workgroup would wait for a CU of its own
+            top_val, top_idx = ops.topk_desc(scores, PRE_NMS, max_slices=TOPK_SLICES_PIPELINED)
             mark("topk", pipe.s_prop)
             boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
             mark("decode_clip_filter", pipe.s_prop)

@@ -60,6 +60,16 @@ size_t frcnn_topk_workspace_bytes(int B, int n, int k);
 int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, float *val_out, int32_t *idx_out,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with a cap on the workgroups an image is split over (max_slices; 0 = the library's choice:
+ * images of more than 8,192 scores are cut into slices that are sorted by one workgroup each and then
+ * merged, about one workgroup per CU; 1 = one workgroup per image).  A caller that runs top-k beside a
+ * kernel which fills the chip's LDS (two batches in flight: objectdetection_amd/pipeline.py) keeps the
+ * split small, because every slice workgroup needs a CU of its own.  No counterpart in the reference
+ * (torch.topk, RPN/rpn.py:65-66); results do not depend on max_slices. */
+int frcnn_topk_desc_ex_f32(const float *scores, int B, int n, int k, float *val_out,
+                           int32_t *idx_out, void *workspace, size_t workspace_bytes,
+                           int max_slices, void *stream);
+
 /* ---- K3 decode / clip / small-box filter -----------------------------------------------------
  * utils.py:173-208 (box_regression, incl. quirk Q1: centre = (w/2, h/2)).
  * box: (n,4); regs: (n,4K) as [dx,dy,dw,dh]xK; out: (n,4K) as [x1,y1,x2,y2]xK. */

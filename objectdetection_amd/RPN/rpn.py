@@ -29,6 +29,9 @@ class RPN(Module):
         self.neg_threshold = dict_params['neg_threshold']
         self.num_sample = dict_params['num_sample']
         self.pos_fraction = dict_params['pos_fraction']
+        # workgroups per image for the top-k (ops.topk_desc): 0 = the library's choice; set to 1 when the
+        # proposal stages run beside RoIAlign on another stream (pipeline.ProposalRoIPipeline)
+        self.topk_max_slices = 0
 
     # -- anchors ---------------------------------------------------------------------------------
     def _flat_anchors(self, batch_image_info, list_features):
@@ -44,7 +47,7 @@ class RPN(Module):
         """-> (props (B,P,4) zero-padded, n_keep (B) int32) on device, no host sync."""
         scores, deltas = ops.rpn_flatten(list_cls, list_regs)                   # rpn.py:56-57
         k = min(self.num_pre_nms, scores.shape[1])                             # rpn.py:65
-        top_val, top_idx = ops.topk_desc(scores, k)                            # rpn.py:66-67
+        top_val, top_idx = ops.topk_desc(scores, k, max_slices=self.topk_max_slices)   # rpn.py:66-67
         boxes, _, _, count = ops.decode_clip_filter(                           # rpn.py:68-69,75,81-83
             anchors, deltas, top_idx, top_val, batch_image_info[1], batch_image_info[2], self.proposal_min_size)
         keep, n_keep = ops.nms_sorted(boxes, count, self.nms_threshold, self.num_post_nms)  # rpn.py:84

@@ -26,6 +26,7 @@ SIGNATURES = {
     "frcnn_rpn_flatten_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "frcnn_topk_workspace_bytes": (_Z, [_I, _I, _I]),
     "frcnn_topk_desc_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "frcnn_topk_desc_ex_f32": (_I, [_P, _I, _I, _I, _P, _P, _P, _Z, _I, _P]),
     "frcnn_box_regression_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "frcnn_box_regression_backward_f32": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "frcnn_box_clip_f32": (_I, [_P, _I, _F, _F, _P, _P]),

@@ -552,10 +552,11 @@ __device__ __forceinline__ unsigned long long wave_match11(unsigned digit, bool 
     return peers;
 }
 
-template <int KR>
-__global__ void __launch_bounds__(TOPK_THREADS)
-topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ val_out,
-                 int32_t *__restrict__ idx_out, uint32_t *__restrict__ ws)
+// sc: the n scores to sort; the first k positions of the result go to idx_out[0..k) (index into sc) and,
+// when val_out is given, val_out[0..k) (the score, or its raw sort key when RAWKEY); ws: 4 n words.
+template <int KR, bool RAWKEY>
+__device__ __forceinline__ void topk_sort_body(const float *__restrict__ sc, int n, int k, uint32_t *__restrict__ val_out,
+                                               int32_t *__restrict__ idx_out, uint32_t *__restrict__ ws)
 {
     __shared__ unsigned s_cnt[TOPK_WAVES][TOPK_SORT_BINS];
     __shared__ unsigned s_base[TOPK_SORT_BINS];
@@ -564,9 +565,7 @@ topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restri
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int b = blockIdx.x;
-    const float *sc = scores + (long long)b * n;
-    uint32_t *keyA = ws + (long long)b * 4 * n;
+    uint32_t *keyA = ws;
     uint32_t *idxA = keyA + n;
     uint32_t *keyB = idxA + n;
     uint32_t *idxB = keyB + n;
@@ -649,8 +648,8 @@ topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restri
                     const unsigned pos = s_base[dg] + off + rank;
                     if (pass == 2) {
                         if (pos < (unsigned)k) {
-                            idx_out[(long long)b * k + pos] = (int32_t)idx;
-                            if (val_out) val_out[(long long)b * k + pos] = frcnn_key_score(kreg[r]);
+                            idx_out[pos] = (int32_t)idx;
+                            if (val_out) val_out[pos] = RAWKEY ? kreg[r] : __float_as_uint(frcnn_key_score(kreg[r]));
                         }
                     } else {
                         kout[pos] = kreg[r];
@@ -666,19 +665,193 @@ topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restri
     }
 }
 
+template <int KR>
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restrict__ val_out,
+                 int32_t *__restrict__ idx_out, uint32_t *__restrict__ ws)
+{
+    const long long b = blockIdx.x;
+    topk_sort_body<KR, false>(scores + b * n, n, k, val_out ? (uint32_t *)val_out + b * k : nullptr, idx_out + b * k,
+                              ws + b * 4 * n);
+}
+
+// ---- split variant: several workgroups per image ---------------------------------------------------
+// One workgroup per image leaves 240 of the 256 CUs idle at batch 16 and all but one at batch 1, and an
+// image of 200,000 scores (FPN) does not fit one workgroup's registers at all.  Here
+// an image is cut into S contiguous slices; slice s is SORTED by its own workgroup (the kernel above, on
+// slice_len scores) which leaves its best min(k, slice length) (key, local index) pairs; then every
+// listed element finds its place in the image's order -- its place in its own list plus, for every other
+// list, the number of elements that go before it -- and, when that is below k, writes itself there.
+// "Before" is the total order of the whole kernel family: larger key first, equal keys by ascending
+// index; slices are index ranges, so against an earlier slice equal keys go first and against a later
+// one they do not.  No atomics, no data-dependent fallback: any distribution costs the same.
+// The merge works a block of 256 consecutive list places at a time: two binary searches per other list
+// (for the block's first and last key) bound a window of that list outside of which nothing changes
+// sides within the block; the windows (about 256 elements each) are staged in LDS and each thread
+// searches them there.  A block whose first element already ranks >= k has nothing to write.
+#define TOPK_MERGE_THREADS 256
+#define TOPK_MERGE_WIN 8192  // words of LDS for the windows; larger windows are searched in global memory
+#define TOPK_MAX_SLICES 64
+
+template <int KR>
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_slice_sort_kernel(const float *__restrict__ scores, int n, int k, int S, int slice_len, int kcap,
+                       uint32_t *__restrict__ ws, uint32_t *__restrict__ skeys, int32_t *__restrict__ sidx)
+{
+    const long long b = blockIdx.x / S;
+    const int s = blockIdx.x % S;
+    const int start = s * slice_len;
+    const int n_s = min(slice_len, n - start);
+    const long long list = (b * S + s) * kcap;
+    topk_sort_body<KR, true>(scores + b * n + start, n_s, min(k, n_s), skeys + list, sidx + list,
+                             ws + b * 4 * n + 4ll * start);
+}
+
+// number of leading elements of a descending list that go before key K: those >= K (or_equal) or > K
+__device__ __forceinline__ int topk_count_before(const uint32_t *list, int len, uint32_t K, bool or_equal)
+{
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const uint32_t v = list[mid];
+        const bool before = or_equal ? v >= K : v > K;
+        lo = before ? mid + 1 : lo;
+        hi = before ? hi : mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(TOPK_MERGE_THREADS)
+topk_merge_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict__ sidx, int n, int k, int S,
+                  int slice_len, int kcap, float *__restrict__ val_out, int32_t *__restrict__ idx_out)
+{
+    __shared__ uint32_t s_win[TOPK_MERGE_WIN];
+    __shared__ int s_posF[TOPK_MAX_SLICES], s_posL[TOPK_MAX_SLICES], s_woff[TOPK_MAX_SLICES + 1];
+    const long long b = blockIdx.z;
+    const int s = blockIdx.y;
+    const int i0 = blockIdx.x * TOPK_MERGE_THREADS;
+    const int len_s = min(k, min(slice_len, n - s * slice_len));
+    if (i0 >= len_s) return;
+    const int iend = min(i0 + TOPK_MERGE_THREADS, len_s);
+    const uint32_t *lists = skeys + b * S * kcap;
+    const uint32_t *mine = lists + (long long)s * kcap;
+    const int t = threadIdx.x;
+    // windows: places of the block's first and last key in every other list
+    for (int q = t; q < 2 * S; q += TOPK_MERGE_THREADS) {
+        const int o = q < S ? q : q - S;
+        int pos = 0;
+        if (o != s) {
+            const uint32_t K = q < S ? mine[i0] : mine[iend - 1];
+            const int len_o = min(k, min(slice_len, n - o * slice_len));
+            pos = topk_count_before(lists + (long long)o * kcap, len_o, K, o < s);
+        }
+        if (q < S) s_posF[o] = pos; else s_posL[o] = pos;
+    }
+    __syncthreads();
+    int rank0 = i0, total = 0;
+    for (int o = 0; o < S; ++o) {
+        rank0 += s_posF[o];
+        total += s_posL[o] - s_posF[o];
+    }
+    if (rank0 >= k) return; // the block's best element is already outside the top k (uniform)
+    const bool fits = total <= TOPK_MERGE_WIN;
+    if (t == 0) {
+        int off = 0;
+        for (int o = 0; o < S; ++o) {
+            s_woff[o] = off;
+            off += s_posL[o] - s_posF[o];
+        }
+        s_woff[S] = off;
+    }
+    __syncthreads();
+    if (fits) {
+        for (int o = 0; o < S; ++o) {
+            const uint32_t *src = lists + (long long)o * kcap + s_posF[o];
+            const int len = s_posL[o] - s_posF[o];
+            for (int q = t; q < len; q += TOPK_MERGE_THREADS) s_win[s_woff[o] + q] = src[q];
+        }
+        __syncthreads();
+    }
+    const int i = i0 + t;
+    if (i >= iend) return;
+    const uint32_t K = mine[i];
+    int rank = i;
+    for (int o = 0; o < S; ++o) {
+        if (o == s) continue;
+        const int len = s_posL[o] - s_posF[o];
+        const uint32_t *win = fits ? s_win + s_woff[o] : lists + (long long)o * kcap + s_posF[o];
+        rank += s_posF[o] + topk_count_before(win, len, K, o < s);
+    }
+    if (rank < k) {
+        idx_out[b * k + rank] = sidx[(b * S + s) * kcap + i] + s * slice_len;
+        if (val_out) val_out[b * k + rank] = frcnn_key_score(K);
+    }
+}
+
 #define TOPK_SORT_KR 21
 static bool topk_use_sort(int n, int k) { return n <= TOPK_SORT_KR * TOPK_THREADS && 2LL * k >= n && n > 8 * TOPK_THREADS; }
+
+// Split plan: slices of at most 21,504 scores, enough of them to give the chip about one workgroup per
+// CU (at most 16 by choice, more only when the image needs them).  Images of up to 8,192 scores stay
+// with one workgroup (register-resident kernels); more than 64 slices (1.37 M scores) with the
+// streaming kernel.
+struct TopkSplit {
+    int S, slice_len, kcap;
+};
+
+static bool topk_split_plan(int B, int n, int k, int max_slices, TopkSplit *p)
+{
+    if (n <= 8 * TOPK_THREADS || B <= 0) return false;
+    const int cap = TOPK_SORT_KR * TOPK_THREADS;
+    int S = (n + cap - 1) / cap; // what the image needs
+    int want = (256 + B - 1) / B;
+    if (want > 16) want = 16;
+    if (max_slices > 0 && want > max_slices) want = max_slices; // the caller's cap on workgroups per image
+    if (S < want) S = want;
+    if (S < 2) return false;
+    if (S > TOPK_MAX_SLICES) return false;
+    int slice_len = (n + S - 1) / S;
+    slice_len = (slice_len + 63) / 64 * 64; // whole wave rounds; the last slice takes what is left
+    S = (n + slice_len - 1) / slice_len;
+    if (S < 2) return false;
+    p->S = S;
+    p->slice_len = slice_len;
+    p->kcap = k < slice_len ? k : slice_len;
+    return true;
+}
 
 extern "C" size_t frcnn_topk_workspace_bytes(int B, int n, int k)
 {
     if (B <= 0 || k <= 0) return 0;
+    // enough for every plan frcnn_topk_desc_ex_f32 can choose: one workgroup per image needs 4 n or 4 k words,
+    // the split path 4 n for the slice sorts plus the slices' lists (keys and indices, at most n rounded up
+    // to whole wave rounds per slice)
+    if (n > 8 * TOPK_THREADS)
+        return (size_t)B * (6 * (size_t)n + 2 * 64 * TOPK_MAX_SLICES) * sizeof(uint32_t);
     const size_t per = topk_use_sort(n, k) ? (size_t)n : (size_t)k;
     return (size_t)B * 4 * per * sizeof(uint32_t);
 }
 
+template <int KR>
+static void topk_launch_slices(const float *scores, int B, int n, int k, const TopkSplit &sp, uint32_t *ws,
+                               uint32_t *skeys, int32_t *sidx, hipStream_t stream)
+{
+    hipLaunchKernelGGL((topk_slice_sort_kernel<KR>), dim3(B * sp.S), dim3(TOPK_THREADS), 0, stream, scores, n, k, sp.S,
+                       sp.slice_len, sp.kcap, ws, skeys, sidx);
+}
+
+extern "C" int frcnn_topk_desc_ex_f32(const float *scores, int B, int n, int k, float *val_out, int32_t *idx_out,
+                                      void *workspace, size_t workspace_bytes, int max_slices, void *stream);
+
 extern "C" int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, float *val_out,
                                    int32_t *idx_out, void *workspace, size_t workspace_bytes,
                                    void *stream)
+{
+    return frcnn_topk_desc_ex_f32(scores, B, n, k, val_out, idx_out, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int frcnn_topk_desc_ex_f32(const float *scores, int B, int n, int k, float *val_out, int32_t *idx_out,
+                                      void *workspace, size_t workspace_bytes, int max_slices, void *stream)
 {
     FRCNN_REQUIRE(B >= 0 && n >= 0 && k >= 0 && k <= n, "topk: bad shape (B=%d n=%d k=%d)", B, n, k);
     if (B == 0 || k == 0) return FRCNN_OK;
@@ -687,6 +860,30 @@ extern "C" int frcnn_topk_desc_f32(const float *scores, int B, int n, int k, flo
         frcnn_set_error("topk: workspace too small (%zu < %zu)", workspace_bytes,
                         frcnn_topk_workspace_bytes(B, n, k));
         return FRCNN_EWORKSPACE;
+    }
+    TopkSplit sp;
+    if (topk_split_plan(B, n, k, max_slices, &sp)) {
+        uint32_t *ws = (uint32_t *)workspace;
+        uint32_t *skeys = ws + (size_t)B * 4 * n;
+        int32_t *sidx = (int32_t *)(skeys + (size_t)B * sp.S * sp.kcap);
+        const int rounds = (sp.slice_len + TOPK_THREADS - 1) / TOPK_THREADS;
+        if (rounds <= 2)
+            topk_launch_slices<2>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
+        else if (rounds <= 4)
+            topk_launch_slices<4>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
+        else if (rounds <= 8)
+            topk_launch_slices<8>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
+        else if (rounds <= 13)
+            topk_launch_slices<13>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
+        else
+            topk_launch_slices<TOPK_SORT_KR>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
+        FRCNN_CHECK_LAUNCH("topk_slice_sort");
+        hipLaunchKernelGGL(topk_merge_kernel,
+                           dim3((sp.kcap + TOPK_MERGE_THREADS - 1) / TOPK_MERGE_THREADS, sp.S, B),
+                           dim3(TOPK_MERGE_THREADS), 0, (hipStream_t)stream, skeys, sidx, n, k, sp.S, sp.slice_len,
+                           sp.kcap, val_out, idx_out);
+        FRCNN_CHECK_LAUNCH("topk_merge");
+        return FRCNN_OK;
     }
     if (topk_use_sort(n, k))
         hipLaunchKernelGGL((topk_sort_kernel<TOPK_SORT_KR>), dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream,

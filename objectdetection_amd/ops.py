@@ -94,8 +94,10 @@ def rpn_flatten(list_cls, list_regs):
     return scores, deltas
 
 
-def topk_desc(scores, k, want_values=True):
-    """Per-row sorted top-k (RPN/rpn.py:65-66).  scores (B,n) -> values (B,k), indices (B,k) int32."""
+def topk_desc(scores, k, want_values=True, max_slices=0):
+    """Per-row sorted top-k (RPN/rpn.py:65-66).  scores (B,n) -> values (B,k), indices (B,k) int32.
+    max_slices caps the workgroups a row is split over (0: the library decides, 1: one per row -- for
+    callers that run beside a chip-filling kernel, see pipeline.py); results do not depend on it."""
     _need_gpu(scores)
     scores = _f32c(scores)
     B, n = scores.shape
@@ -108,7 +110,8 @@ def topk_desc(scores, k, want_values=True):
     nbytes = lib.frcnn_topk_workspace_bytes(B, n, k)
     ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.frcnn_topk_desc_f32(_ptr(scores), B, n, k, _ptr(vals), _ptr(idx), _ptr(ws), nbytes, _stream())
+        rc = lib.frcnn_topk_desc_ex_f32(_ptr(scores), B, n, k, _ptr(vals), _ptr(idx), _ptr(ws), nbytes,
+                                        int(max_slices), _stream())
     _lib.check(rc, "topk_desc")
     return vals, idx
 

@@ -247,6 +247,45 @@ def test_topk_ties_and_specials(dev, oracle):
             assert_bits_equal(vals[b].cpu().numpy(), v)
 
 
+@pytest.mark.parametrize("kind", ["tie_free", "all_equal", "two_values", "ascending", "descending", "specials"])
+@pytest.mark.parametrize("B,n,k", [(1, 8193, 100), (2, 20646, 12000), (1, 50000, 50000), (3, 50000, 300),
+                                   (1, 200907, 30000), (16, 9000, 4500)])
+def test_topk_split_matches_single_workgroup(dev, oracle, kind, B, n, k):
+    """The multi-workgroup path (slice sorts + windowed merge) against one workgroup per image and the
+    oracle, whatever the split: adversarial key distributions make the merge windows empty (tie-free,
+    sorted inputs), huge (all keys equal: the windows do not fit LDS and are searched in global memory)
+    or lopsided."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(n * 7 + k)
+    if kind == "tie_free":
+        s = np.stack([tie_free_scores(rng, n) for _ in range(B)])
+    elif kind == "all_equal":
+        s = np.full((B, n), 0.375, np.float32)
+    elif kind == "two_values":
+        s = rng.integers(0, 2, (B, n)).astype(np.float32)
+    elif kind == "ascending":
+        s = np.tile(np.arange(n, dtype=np.float32) * 0.5, (B, 1))
+    elif kind == "descending":
+        s = np.tile(-np.arange(n, dtype=np.float32), (B, 1))
+    else:
+        s = rng.integers(-30, 31, (B, n)).astype(np.float32) * 0.125
+        s[:, ::89] = np.nan
+        s[:, 3::97] = -0.0
+        s[:, 6::131] = np.inf
+        s[:, 9::137] = -np.inf
+    dev_s = T(s, dev)
+    ref_v, ref_i = ops.topk_desc(dev_s, k, max_slices=1)
+    v0, i0 = oracle.topk(s[0], k)
+    assert np.array_equal(ref_i[0].cpu().numpy(), i0)
+    assert_bits_equal(ref_v[0].cpu().numpy(), v0)
+    for max_slices in (0, 2, 5, 64):
+        v, i = ops.topk_desc(dev_s, k, max_slices=max_slices)
+        assert torch.equal(i, ref_i), (kind, max_slices)
+        assert_bits_equal(v.cpu().numpy(), ref_v.cpu().numpy())
+    _, i = ops.topk_desc(dev_s, k, want_values=False)
+    assert torch.equal(i, ref_i)
+
+
 def test_rpn_stages_golden(dev):
     """RPN/rpn.py:55-83 on the HIP path vs what the reference's own functions produced."""
     from objectdetection_amd import ops
