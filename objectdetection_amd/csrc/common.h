@@ -103,6 +103,21 @@ __device__ __forceinline__ bool frcnn_iou_gt(float inter, float uni, const Frcnn
     return r;
 }
 
+// Kernel attributes are per device: remember, per device, the largest dynamic-LDS size already granted to a
+// kernel.  `granted` is a static array of the call site, one per kernel.
+#define FRCNN_MAX_DEVICES 64
+static inline hipError_t frcnn_reserve_dynamic_lds(const void *kernel, size_t bytes, size_t (&granted)[FRCNN_MAX_DEVICES])
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < FRCNN_MAX_DEVICES;
+    if (tracked && bytes <= granted[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && tracked) granted[dev] = bytes;
+    return e;
+}
+
 // Order-preserving unsigned key of an fp32 score: larger key = ranks first.
 // NaN -> 0xFFFFFFFF (above +inf, as torch.topk treats NaN), -0.0 below +0.0.
 __device__ __forceinline__ uint32_t frcnn_score_key(float s)

@@ -543,13 +543,10 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
 
     if (max_n <= NMS_LAZY_MAX_N) { // kept list (24 B per keep) fits LDS: one launch
         const size_t lazy_lds = (size_t)cap * 24;
-        static size_t configured = 48 * 1024;
-        if (lazy_lds > configured) {
-            hipError_t e = hipFuncSetAttribute((const void *)nms_lazy_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               NMS_LAZY_MAX_N * 24);
+        if (lazy_lds > 48 * 1024) {
+            static size_t granted[FRCNN_MAX_DEVICES];
+            hipError_t e = frcnn_reserve_dynamic_lds((const void *)nms_lazy_kernel, NMS_LAZY_MAX_N * 24, granted);
             FRCNN_REQUIRE(e == hipSuccess, "nms: cannot reserve LDS: %s", hipGetErrorString(e));
-            configured = NMS_LAZY_MAX_N * 24;
         }
         hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
                            (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out,

@@ -913,15 +913,12 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         size_t lds = (size_t)plane_bytes * (size_t)CC;
         // fast instantiation: full 16-channel chunks on a map at most 64 pixels wide
         const bool full = (CC == 16) && (C % 16 == 0) && WS == 64;
-        static size_t configured4 = 0, configured0 = 0;
-        size_t &configured = full ? configured4 : configured0;
-        if (lds > configured) {
-            hipError_t e = hipFuncSetAttribute(
-                full ? (const void *)roi_align_plane_kernel<4, 64> : (const void *)roi_align_plane_kernel<0, 0>,
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        {
+            static size_t granted4[FRCNN_MAX_DEVICES], granted0[FRCNN_MAX_DEVICES];
+            hipError_t e = full ? frcnn_reserve_dynamic_lds((const void *)roi_align_plane_kernel<4, 64>, lds, granted4)
+                                : frcnn_reserve_dynamic_lds((const void *)roi_align_plane_kernel<0, 0>, lds, granted0);
             FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
                           hipGetErrorString(e));
-            configured = lds;
         }
         const long long groups8 = ((long long)splits * B + 7) / 8 * 8; // (image, split) groups, padded (see kernel)
         FRCNN_REQUIRE(groups8 * chunks < (1ll << 31), "roi_align_batched: grid too large");
@@ -953,15 +950,13 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
             chunks16 = chunks16 < 1 ? 1 : (chunks16 > chunks ? chunks : chunks16);
             const size_t lds = (size_t)RAW_WIN * RAW_WIN * 16 * RAW_G;
             const bool full = C % (4 * RAW_G) == 0;
-            static bool configured4 = false, configured0 = false;
-            bool &configured = full ? configured4 : configured0;
-            if (!configured) {
-                hipError_t e = hipFuncSetAttribute(
-                    full ? (const void *)roi_align_window_kernel<RAW_G> : (const void *)roi_align_window_kernel<0>,
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            {
+                static size_t grantedg[FRCNN_MAX_DEVICES], granted0[FRCNN_MAX_DEVICES];
+                hipError_t e =
+                    full ? frcnn_reserve_dynamic_lds((const void *)roi_align_window_kernel<RAW_G>, lds, grantedg)
+                         : frcnn_reserve_dynamic_lds((const void *)roi_align_window_kernel<0>, lds, granted0);
                 FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
                               hipGetErrorString(e));
-                configured = true;
             }
             const long long groups8 = ((long long)nwy * nwx * B + 7) / 8 * 8;
             FRCNN_REQUIRE(groups8 * chunks16 < (1ll << 31), "roi_align_batched: grid too large");

@@ -690,7 +690,7 @@ topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restri
 // sides within the block; the windows (about 256 elements each) are staged in LDS and each thread
 // searches them there.  A block whose first element already ranks >= k has nothing to write.
 #define TOPK_MERGE_THREADS 256
-#define TOPK_MERGE_WIN 8192  // words of LDS for the windows; larger windows are searched in global memory
+#define TOPK_MERGE_WIN 5120  // words of LDS for the windows (15 x 256 typical); larger windows are searched in global memory
 #define TOPK_MAX_SLICES 64
 
 template <int KR>
@@ -721,6 +721,42 @@ __device__ __forceinline__ int topk_count_before(const uint32_t *list, int len, 
     return lo;
 }
 
+// Sum over the other lists o of posF[o] + (number of elements of window o that go before K).  Window o is
+// base[start(o) .. start(o) + posL[o] - posF[o]) with start(o) = woff[o] (windows staged back to back) or
+// o * stride + posF[o] (the lists themselves).  "v goes before K" is v >= K against an earlier slice and
+// v > K against a later one, i.e. v > K - 1 and v > K (a key is never 0: -inf maps to 0x007FFFFF).
+__device__ __forceinline__ int topk_merge_count(const uint32_t *__restrict__ base, const int *woff, const int *lstart,
+                                                int stride, const int *posF, const int *posL, int S, int s, uint32_t K,
+                                                int top)
+{
+    int sum = 0;
+    for (int o0 = 0; o0 < S; o0 += 4) {
+        int cnt[4], len[4];
+        const uint32_t *win[4];
+        uint32_t thr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int o = o0 + u;
+            const bool valid = o < S && o != s;
+            const int oc = o < S ? o : 0;
+            len[u] = valid ? posL[oc] - posF[oc] : 0;
+            win[u] = base + (woff ? (long long)woff[oc] : (long long)oc * stride + lstart[oc]) - 1; // win[h] = element h - 1
+            thr[u] = o < s ? K - 1u : K;
+            cnt[u] = 0;
+            sum += valid ? posF[oc] : 0;
+        }
+        for (int h = top; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pos = cnt[u] + h;
+                if (pos <= len[u]) cnt[u] = win[u][pos] > thr[u] ? pos : cnt[u];
+            }
+        }
+        sum += cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    }
+    return sum;
+}
+
 __global__ void __launch_bounds__(TOPK_MERGE_THREADS)
 topk_merge_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict__ sidx, int n, int k, int S,
                   int slice_len, int kcap, float *__restrict__ val_out, int32_t *__restrict__ idx_out)
@@ -736,16 +772,45 @@ topk_merge_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict_
     const uint32_t *lists = skeys + b * S * kcap;
     const uint32_t *mine = lists + (long long)s * kcap;
     const int t = threadIdx.x;
-    // windows: places of the block's first and last key in every other list
-    for (int q = t; q < 2 * S; q += TOPK_MERGE_THREADS) {
-        const int o = q < S ? q : q - S;
-        int pos = 0;
-        if (o != s) {
-            const uint32_t K = q < S ? mine[i0] : mine[iend - 1];
-            const int len_o = min(k, min(slice_len, n - o * slice_len));
-            pos = topk_count_before(lists + (long long)o * kcap, len_o, K, o < s);
+    // windows: places of the block's first and last key in every other list.  A search is a chain of
+    // dependent loads, so 16 lanes share one and test 16 places per step (3-4 steps instead of 11-15).
+    // this thread's own element first: its loads are in flight while the windows are found
+    const int i = i0 + t;
+    const uint32_t K = i < iend ? mine[i] : 0u;
+    const int my_idx = i < iend ? sidx[(b * S + s) * kcap + i] : 0;
+    __shared__ uint32_t s_kfl[2];
+    if (t == 0) s_kfl[0] = K;
+    if (i == iend - 1) s_kfl[1] = K;
+    __syncthreads();
+    {
+        const uint32_t Kf = s_kfl[0], Kl = s_kfl[1];
+        const int grp = t >> 4, j = t & 15;
+        for (int q0 = 0; q0 < 2 * S; q0 += TOPK_MERGE_THREADS / 16) {
+            const int q = q0 + grp;
+            const bool live = q < 2 * S;
+            const int o = live ? (q < S ? q : q - S) : s;
+            const uint32_t K = q < S ? Kf : Kl;
+            const uint32_t *list = lists + (long long)o * kcap;
+            const bool or_equal = o < s;
+            int lo = 0, hi = o == s ? 0 : min(k, min(slice_len, n - o * slice_len));
+            while (__any(hi > lo)) {
+                const int w = hi - lo;
+                const int qj = lo + (int)(((long long)(j + 1) * w) >> 4); // a boundary in [lo, hi]
+                bool before = true;                                       // boundary lo is known
+                if (qj > lo) {
+                    const uint32_t v = list[qj - 1];
+                    before = or_equal ? v >= K : v > K;
+                }
+                const unsigned m16 = (unsigned)(__ballot(before) >> (t & 48)) & 0xFFFFu; // true for a prefix of lanes
+                const int m = __popc(m16);
+                const int lo_n = __shfl(qj, m > 0 ? m - 1 : 0, 16), hi_n = __shfl(qj - 1, m < 16 ? m : 15, 16);
+                lo = m > 0 ? lo_n : lo;
+                hi = m < 16 ? hi_n : hi;
+            }
+            if (live && j == 0) {
+                if (q < S) s_posF[o] = lo; else s_posL[o] = lo;
+            }
         }
-        if (q < S) s_posF[o] = pos; else s_posL[o] = pos;
     }
     __syncthreads();
     int rank0 = i0, total = 0;
@@ -765,25 +830,30 @@ topk_merge_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict_
     }
     __syncthreads();
     if (fits) {
-        for (int o = 0; o < S; ++o) {
-            const uint32_t *src = lists + (long long)o * kcap + s_posF[o];
-            const int len = s_posL[o] - s_posF[o];
-            for (int q = t; q < len; q += TOPK_MERGE_THREADS) s_win[s_woff[o] + q] = src[q];
+        // one flat loop over all windows: the loads of different lists are independent and in flight together
+        // (a loop per list cost one memory round trip per list)
+        const int total_w = s_woff[S];
+#pragma unroll 4
+        for (int f = t; f < total_w; f += TOPK_MERGE_THREADS) {
+            int o = 0;
+            while (f >= s_woff[o + 1]) ++o;
+            s_win[f] = lists[(long long)o * kcap + s_posF[o] + (f - s_woff[o])];
         }
         __syncthreads();
     }
-    const int i = i0 + t;
     if (i >= iend) return;
-    const uint32_t K = mine[i];
-    int rank = i;
-    for (int o = 0; o < S; ++o) {
-        if (o == s) continue;
-        const int len = s_posL[o] - s_posF[o];
-        const uint32_t *win = fits ? s_win + s_woff[o] : lists + (long long)o * kcap + s_posF[o];
-        rank += s_posF[o] + topk_count_before(win, len, K, o < s);
-    }
+    int rank = i, top = 1;
+    for (int o = 0; o < S; ++o)
+        while (2 * top <= s_posL[o] - s_posF[o]) top *= 2;
+    // four lists at a time, their (dependent) reads interleaved; count = sum of accepted powers of two.
+    // Two instantiations so that the LDS case compiles to ds_read, not to flat loads through a pointer
+    // that may be either.
+    if (fits)
+        rank += topk_merge_count(s_win, s_woff, nullptr, 0, s_posF, s_posL, S, s, K, top);
+    else
+        rank += topk_merge_count(lists, nullptr, s_posF, kcap, s_posF, s_posL, S, s, K, top);
     if (rank < k) {
-        idx_out[b * k + rank] = sidx[(b * S + s) * kcap + i] + s * slice_len;
+        idx_out[b * k + rank] = my_idx + s * slice_len;
         if (val_out) val_out[b * k + rank] = frcnn_key_score(K);
     }
 }
@@ -792,7 +862,7 @@ topk_merge_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict_
 static bool topk_use_sort(int n, int k) { return n <= TOPK_SORT_KR * TOPK_THREADS && 2LL * k >= n && n > 8 * TOPK_THREADS; }
 
 // Split plan: slices of at most 21,504 scores, enough of them to give the chip about one workgroup per
-// CU (at most 16 by choice, more only when the image needs them).  Images of up to 8,192 scores stay
+// CU (at most 8 by choice -- the merge does one search per other slice -- more only when the image needs them).  Images of up to 8,192 scores stay
 // with one workgroup (register-resident kernels); more than 64 slices (1.37 M scores) with the
 // streaming kernel.
 struct TopkSplit {
@@ -805,7 +875,7 @@ static bool topk_split_plan(int B, int n, int k, int max_slices, TopkSplit *p)
     const int cap = TOPK_SORT_KR * TOPK_THREADS;
     int S = (n + cap - 1) / cap; // what the image needs
     int want = (256 + B - 1) / B;
-    if (want > 16) want = 16;
+    if (want > 8) want = 8; // measured: 0.116 / 0.078 / 0.054 / 0.048 / 0.059 ms at 1 / 2 / 4 / 8 / 16 slices (16 x 20,646)
     if (max_slices > 0 && want > max_slices) want = max_slices; // the caller's cap on workgroups per image
     if (S < want) S = want;
     if (S < 2) return false;
