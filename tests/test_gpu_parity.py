@@ -608,6 +608,33 @@ def test_roi_align_shape_sweep(dev, oracle):
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,C,hw", [(3, 512, (37, 62)), (5, 256, (37, 62)), (7, 64, (50, 84)), (3, 32, (100, 168))])
+def test_roi_align_block_order_padding(dev, oracle, B, C, hw):
+    """The 1-D, XCD-grouped grids of the plane and window kernels pad the number of (image, split) or
+    (window, image) groups to a multiple of 8: batch sizes for which that padding is not empty."""
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    rng = np.random.default_rng(B * 1000 + C)
+    h, w = hw
+    stride = 16 if h < 60 else 8
+    Himg, Wimg = h * stride, w * stride
+    feat = rng.standard_normal((B, C, h, w)).astype(np.float32)
+    P = 40
+    counts = [int(rng.integers(1, P + 1)) for _ in range(B)]
+    padded = np.zeros((B, P, 4), np.float32)
+    props = []
+    for b, n in enumerate(counts):
+        sz = np.exp(rng.uniform(np.log(8), np.log(min(Himg, Wimg) * 0.6), (n, 2)))
+        c = rng.uniform(0.05, 0.95, (n, 2)) * [Wimg, Himg]
+        p = np.concatenate([c - sz / 2, c + sz / 2], 1).astype(np.float32)
+        props.append(p)
+        padded[b, :n] = p
+    ref, _ = oracle.multiscale_roi_align([feat], props, [(Himg, Wimg)], (7, 7), 2)
+    pool = ROIPooling(['1'], [7, 7], 2)
+    out, total = pool.forward_padded({'1': T(feat, dev)}, T(padded, dev), T(counts, dev, torch.int32), [(Himg, Wimg)])
+    assert int(total) == sum(counts)
+    np.testing.assert_allclose(out[:sum(counts)].cpu().numpy(), ref, rtol=RTOL, atol=2e-5)
+
+
 def test_nms_size_sweep(dev, oracle):
     """Seeded sweep over candidate counts around the lazy / round boundaries and keep budgets."""
     from objectdetection_amd import ops
