@@ -278,7 +278,7 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
                roofline=dict(bound="hbm", kernel="roi_align_plane_kernel", achieved=roi_bytes / (ra_ms * 1e-3) / 1e9,
                              peak=HBM_PEAK_GBPS, unit="GB/s", frac=roi_bytes / (ra_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              traffic=traffic, traffic_source="pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE, "
-                             "separate passes; profiles/r01_step2_roi_align_pmc.csv)" if traffic else None,
+                             "separate passes; profiles/r01_step6_roi_align_pmc.csv)" if traffic else None,
                              algorithmic_bytes_per_launch=roi_bytes, launch_ms=ra_ms,
                              dominant_stage=max(stage_ms, key=stage_ms.get)))
     return res, props, n_keep
@@ -342,6 +342,7 @@ def main():
         extras.update(nms_microbench(path, dev))
         extras.update(next_rows_microbench(dev))
         extras.update(targets_microbench(path, dev))
+        extras.update(roi_pool_microbench(path, dev))
         extras.update(config5_microbench(dev))
         extras.update(hbm_probe(dev))
 
@@ -610,6 +611,33 @@ def config5_microbench(dev, B=16, reps=5):
         "rois_per_step": int(total), "keeps_per_img_mean": float(nk.float().mean()),
         "roi_align_write_GBps": out_bytes / (stage["roi_align"] * 1e-3) / 1e9,
         "roi_align_hbm_frac": out_bytes / (stage["roi_align"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+
+
+def roi_pool_microbench(path, dev):
+    """K7, torchvision roi_pool (max) semantics -- not called by the reference (north_star extra): 2,000 RoIs of
+    one image, C = 512, 7x7: write C*49*8 B per RoI (values + int32 argmax)."""
+    ops = path.ops
+    rng = np.random.default_rng(11)
+    K = POST_NMS
+    cx, cy = rng.uniform(0, IMG_W, K), rng.uniform(0, IMG_H, K)
+    w, h = 16 * 2 ** rng.uniform(0, 5, K), 16 * 2 ** rng.uniform(0, 5, K)
+    rois = np.stack([np.zeros(K), (cx - w / 2).clip(0, IMG_W), (cy - h / 2).clip(0, IMG_H), (cx + w / 2).clip(0, IMG_W),
+                     (cy + h / 2).clip(0, IMG_H)], 1).astype(np.float32)
+    rois = torch.as_tensor(rois).to(dev)
+    feat = torch.randn((1, C, FH, FW), generator=torch.Generator().manual_seed(5)).to(dev)
+    for _ in range(2):
+        ops.roi_pool(feat, rois, (7, 7), 1.0 / 16)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 5
+    for _ in range(reps):
+        ops.roi_pool(feat, rois, (7, 7), 1.0 / 16)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = K * C * 49 * 8 + C * FH * FW * 4
+    return {"roi_pool_max_K2000_C512": {"ms": ms, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
+                                        "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
 
 
 def nms_microbench(path, dev):
