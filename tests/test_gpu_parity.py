@@ -314,6 +314,36 @@ def test_rpn_stages_golden(dev):
         assert_bits_equal(fscores[b, :c].cpu().numpy(), g[f"b{b}.filtered_score"])
 
 
+@pytest.mark.parametrize("B,A,k,min_size", [(3, 20646, 12000, 40.0), (2, 20646, 12000, 1e-3), (2, 5000, 1024, 30.0),
+                                            (1, 5000, 1025, 30.0), (2, 3000, 700, 25.0), (1, 70000, 30000, 60.0),
+                                            (2, 9000, 4096, 1e9)])
+def test_decode_clip_filter_gaps(dev, B, A, k, min_size):
+    """Fused decode / clip / small-box filter with many rows dropped in every tile (the gap-closing pass),
+    with none dropped, with all dropped, and at the tile boundaries: against the same stages done one by
+    one (box_regression, box_clip, remove_small_box -- each pinned by the reference's goldens)."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(A + k)
+    anchors = T(realistic_boxes(rng, A), dev)
+    deltas = T((rng.standard_normal((B, A, 4)) * 0.4).astype(np.float32), dev)
+    top_idx = T(np.stack([rng.permutation(A)[:k] for _ in range(B)]).astype(np.int32), dev, torch.int32)
+    top_score = T(rng.standard_normal((B, k)).astype(np.float32), dev)
+    boxes, scores, src, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_score, 600.0, 1000.0, min_size)
+    cnt = count.cpu().numpy()
+    for b in range(B):
+        sel = top_idx[b].long()
+        dec = ops.box_clip(ops.box_regression(anchors[sel], deltas[b][sel]), 600.0, 1000.0)
+        kept, index, n = ops.remove_small_box(dec, min_size)
+        n = int(n)
+        assert int(cnt[b]) == n
+        assert torch.equal(src[b, :n].long(), index[:n].long())
+        assert_bits_equal(boxes[b, :n].cpu().numpy(), kept[:n].cpu().numpy())
+        assert_bits_equal(scores[b, :n].cpu().numpy(), top_score[b][index[:n].long()].cpu().numpy())
+    if min_size > 1e8:
+        assert (cnt == 0).all()
+    elif min_size > 1:
+        assert ((cnt > 0) & (cnt < k)).all()
+
+
 # ---------------------------------------------------------------------------------- NMS (K4)
 def lattice_boxes(n):
     side = int(np.ceil(np.sqrt(n)))
