@@ -190,6 +190,30 @@ __global__ void __launch_bounds__(1024) shape_xcd_kernel(float *out, int P, int 
     }
 }
 
+// modes 35-37: as mode 29 (XCD-grouped, dword runs) but WPR waves share one RoI (each writes 16 / WPR of
+// its 16 channels), i.e. fewer output rows in flight per workgroup.
+template <int WPR>
+__global__ void __launch_bounds__(1024) shape_xcd_share_kernel(float *out, int P, int C, int splits)
+{
+    const int cpr = C / 16;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int chunk = slot % cpr;
+    const int grp = (slot / cpr) * 8 + xcd;
+    const int split = grp % splits, b = grp / splits;
+    const int per = (P + splits - 1) / splits;
+    const int j0 = split * per, j1 = min(P, j0 + per);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int part = wave % WPR, team = wave / WPR;
+    for (int jl = team; jl < j1 - j0; jl += 16 / WPR) {
+        float *o = out + (((long long)b * P + j0 + jl) * C + chunk * 16) * 49;
+        if (lane < 49) {
+#pragma unroll
+            for (int c = 0; c < 16 / WPR; ++c) o[(part * (16 / WPR) + c) * 49 + lane] = (float)c;
+        }
+    }
+}
+
 // mode 23: the item pattern of mode 16, but each WAVE walks a contiguous range of whole RoIs (64 items per
 // iteration), so the two parts of a RoI that straddles an iteration are written by the same wave back to back.
 __global__ void __launch_bounds__(1024) item_seq_kernel(float *out, int P, int C, int rois_per_wave)
@@ -238,7 +262,7 @@ int main()
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     const int reps = 10;
-    for (int mode = 0; mode < 35; ++mode) {
+    for (int mode = 0; mode < 38; ++mode) {
         float ms = 0;
         for (int r = -2; r < reps; ++r) {
             if (r == 0) CHECK(hipEventRecord(e0, 0));
@@ -268,6 +292,9 @@ int main()
             case 24: hipLaunchKernelGGL(item_seq_kernel, dim3(32, 2, B), dim3(1024), 0, 0, (float *)out, P, C, 64); break;
             case 25: hipLaunchKernelGGL(item_seq_kernel, dim3(32, 2, B), dim3(1024), 0, 0, (float *)out, P, C, 4); break;
             case 11: hipLaunchKernelGGL(piece_kernel, dim3(32, 1, B), dim3(1024), 0, 0, out, P, 196, 32); break;
+            case 35: hipLaunchKernelGGL((shape_xcd_share_kernel<2>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
+            case 36: hipLaunchKernelGGL((shape_xcd_share_kernel<4>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
+            case 37: hipLaunchKernelGGL((shape_xcd_share_kernel<16>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
             case 29: hipLaunchKernelGGL((shape_xcd_kernel<1>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
             case 30: hipLaunchKernelGGL((shape_xcd_kernel<2>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
             case 31: hipLaunchKernelGGL((shape_xcd_kernel<3>), dim3(32 * 2 * B), dim3(1024), 0, 0, (float *)out, P, C, 2); break;
