@@ -249,7 +249,7 @@ def test_topk_ties_and_specials(dev, oracle):
 
 @pytest.mark.parametrize("kind", ["tie_free", "all_equal", "two_values", "ascending", "descending", "specials"])
 @pytest.mark.parametrize("B,n,k", [(1, 8193, 100), (2, 20646, 12000), (1, 50000, 50000), (3, 50000, 300),
-                                   (1, 200907, 30000), (16, 9000, 4500)])
+                                   (1, 200907, 30000), (16, 9000, 4500), (1, 805707, 30000), (2, 1300000, 5000)])
 def test_topk_split_matches_single_workgroup(dev, oracle, kind, B, n, k):
     """The multi-workgroup path (slice sorts + windowed merge) against one workgroup per image and the
     oracle, whatever the split: adversarial key distributions make the merge windows empty (tie-free,
