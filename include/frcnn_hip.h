@@ -101,7 +101,8 @@ int frcnn_select_gt_f32(const float *value, int n, float thresh, int64_t *index_
  * anchors: (A,4) shared by the batch when anchor_batch_stride == 0, else (B,A,4) with that
  * element stride; deltas: (B,A,4); top_idx/top_score: (B,k).
  * boxes_out: (B,k,4); scores_out: (B,k); src_out: (B,k) position in the top-k list of each kept
- * row (= remove_small_box's index); count_out: (B) kept rows per image. */
+ * row (= remove_small_box's index); count_out: (B) kept rows per image.  Rows at and beyond an image's
+ * count are unspecified (src_out may hold -1 there). */
 int frcnn_decode_clip_filter_f32(const float *anchors, int64_t anchor_batch_stride,
                                  const float *deltas, const int32_t *top_idx,
                                  const float *top_score, int B, int A, int k, float image_h,
