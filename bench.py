@@ -111,6 +111,8 @@ class Path:
         # of the chip idle) of batch i+1 run while RoIAlign (the whole chip, store-bound) of batch i drains
         from objectdetection_amd.pipeline import ProposalRoIPipeline
         self.pipe = ProposalRoIPipeline(dev)
+        # BENCH_FLATTEN=1: the three-launch form with flattened copies (rpn_flatten + topk_desc + decode)
+        self.in_place = os.environ.get("BENCH_FLATTEN", "0") != "1"
 
     def anchors(self, batch, feat):
         return torch.cat([a[0].reshape(-1, 4) for a in self.ag((batch, IMG_H, IMG_W), [feat])], 0)
@@ -128,12 +130,18 @@ class Path:
                 ev.append((name, e))
 
         mark("start")
-        scores, deltas = ops.rpn_flatten([cls], [reg])
-        mark("flatten")
-        top_val, top_idx = ops.topk_desc(scores, PRE_NMS)
-        mark("topk")
-        boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
-        mark("decode_clip_filter")
+        if self.in_place:  # RPN/rpn.py:56-57 never materialised: the head's NCHW outputs are read where they lie
+            top_val, top_idx = ops.topk_desc_nchw([cls], PRE_NMS)
+            mark("topk")
+            boxes, _, _, count = ops.decode_clip_filter_nchw(anchors, [reg], top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
+            mark("decode_clip_filter")
+        else:
+            scores, deltas = ops.rpn_flatten([cls], [reg])
+            mark("flatten")
+            top_val, top_idx = ops.topk_desc(scores, PRE_NMS)
+            mark("topk")
+            boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
+            mark("decode_clip_filter")
         keep, n_keep = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
         mark("nms")
         props = ops.gather_boxes(boxes, keep, n_keep)
@@ -590,12 +598,18 @@ def config5_microbench(dev, B=16, reps=5):
             e.record()
             ev.append((n, e))
         mark("start")
-        scores, deltas = ops.rpn_flatten(x["cls"], x["reg"])
-        mark("flatten")
-        tv, ti = ops.topk_desc(scores, 30000)
-        mark("topk")
-        boxes, _, _, count = ops.decode_clip_filter(x["anchors"], deltas, ti, tv, x["Himg"], x["Wimg"], 1e-3)
-        mark("decode_clip_filter")
+        if os.environ.get("BENCH_FLATTEN", "0") != "1":
+            tv, ti = ops.topk_desc_nchw(x["cls"], 30000)
+            mark("topk")
+            boxes, _, _, count = ops.decode_clip_filter_nchw(x["anchors"], x["reg"], ti, tv, x["Himg"], x["Wimg"], 1e-3)
+            mark("decode_clip_filter")
+        else:
+            scores, deltas = ops.rpn_flatten(x["cls"], x["reg"])
+            mark("flatten")
+            tv, ti = ops.topk_desc(scores, 30000)
+            mark("topk")
+            boxes, _, _, count = ops.decode_clip_filter(x["anchors"], deltas, ti, tv, x["Himg"], x["Wimg"], 1e-3)
+            mark("decode_clip_filter")
         keep, nk = ops.nms_sorted(boxes, count, 0.7, 2000)
         mark("nms")
         props = ops.gather_boxes(boxes, keep, nk)

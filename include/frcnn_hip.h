@@ -110,6 +110,25 @@ int frcnn_decode_clip_filter_f32(const float *anchors, int64_t anchor_batch_stri
                                  float *scores_out, int32_t *src_out, int32_t *count_out,
                                  void *stream);
 
+/* RPN/rpn.py:56-57 + 65-66 and 67-69,75,81-83 WITHOUT the flattened copies: the same two stages reading the
+ * head's NCHW outputs where they lie.  cls_host / reg_host: HOST arrays of n_levels (<= 6) device pointers,
+ * (B,na,h,w) scores and (B,4na,h,w) deltas; hw_host: HOST array (n_levels,2) of (h,w); flat element index
+ * = level offset + cell*na + a, as frcnn_rpn_flatten_f32 lays it out, A = na * sum(h*w).
+ * frcnn_topk_desc_nchw_f32 covers the sizes the split top-k covers (frcnn_topk_desc_nchw_supported != 0:
+ * A > 8192 and max_slices != 1); other sizes flatten first.  Results are bit-identical to the flattened
+ * path.  workspace: frcnn_topk_workspace_bytes(B, A, k). */
+int frcnn_topk_desc_nchw_supported(int B, int A, int k, int max_slices);
+int frcnn_topk_desc_nchw_f32(const float *const *cls_host, const int32_t *hw_host, int n_levels, int na,
+                             int B, int k, float *val_out, int32_t *idx_out, void *workspace,
+                             size_t workspace_bytes, int max_slices, void *stream);
+int frcnn_decode_clip_filter_nchw_f32(const float *anchors, int64_t anchor_batch_stride,
+                                      const float *const *reg_host, const int32_t *hw_host,
+                                      int n_levels, int na, const int32_t *top_idx,
+                                      const float *top_score, int B, int k, float image_h,
+                                      float image_w, float min_size, float *boxes_out,
+                                      float *scores_out, int32_t *src_out, int32_t *count_out,
+                                      void *stream);
+
 /* ---- K4 NMS ----------------------------------------------------------------------------------
  * torchvision.ops.nms as called at RPN/rpn.py:84 and ROIHead/roi_head.py:215, batched.
  * boxes: (B, max_n, 4), each image's rows ALREADY in candidate order (descending score);

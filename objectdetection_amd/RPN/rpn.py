@@ -45,11 +45,19 @@ class RPN(Module):
     # -- proposal half: RPN/rpn.py:54-85 ----------------------------------------------------------
     def proposals_from_head(self, batch_image_info, anchors, list_cls, list_regs):
         """-> (props (B,P,4) zero-padded, n_keep (B) int32) on device, no host sync."""
-        scores, deltas = ops.rpn_flatten(list_cls, list_regs)                   # rpn.py:56-57
-        k = min(self.num_pre_nms, scores.shape[1])                             # rpn.py:65
-        top_val, top_idx = ops.topk_desc(scores, k, max_slices=self.topk_max_slices)   # rpn.py:66-67
-        boxes, _, _, count = ops.decode_clip_filter(                           # rpn.py:68-69,75,81-83
-            anchors, deltas, top_idx, top_val, batch_image_info[1], batch_image_info[2], self.proposal_min_size)
+        A = sum(c.shape[1] * c.shape[2] * c.shape[3] for c in list_cls)
+        k = min(self.num_pre_nms, A)                                           # rpn.py:65
+        info = batch_image_info
+        if ops.rpn_in_place_supported(list_cls, k, self.topk_max_slices):
+            # rpn.py:56-57 never materialised: top-k and decode read the head's NCHW outputs where they lie
+            top_val, top_idx = ops.topk_desc_nchw(list_cls, k, max_slices=self.topk_max_slices)   # rpn.py:66-67
+            boxes, _, _, count = ops.decode_clip_filter_nchw(                  # rpn.py:68-69,75,81-83
+                anchors, list_regs, top_idx, top_val, info[1], info[2], self.proposal_min_size)
+        else:
+            scores, deltas = ops.rpn_flatten(list_cls, list_regs)               # rpn.py:56-57
+            top_val, top_idx = ops.topk_desc(scores, k, max_slices=self.topk_max_slices)   # rpn.py:66-67
+            boxes, _, _, count = ops.decode_clip_filter(                       # rpn.py:68-69,75,81-83
+                anchors, deltas, top_idx, top_val, info[1], info[2], self.proposal_min_size)
         keep, n_keep = ops.nms_sorted(boxes, count, self.nms_threshold, self.num_post_nms)  # rpn.py:84
         props = ops.gather_boxes(boxes, keep, n_keep)                          # rpn.py:85
         return props, n_keep

@@ -33,6 +33,10 @@ SIGNATURES = {
     "frcnn_remove_small_box_f32": (_I, [_P, _I, _F, _P, _P, _P, _P]),
     "frcnn_select_gt_f32": (_I, [_P, _I, _F, _P, _P, _P]),
     "frcnn_decode_clip_filter_f32": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P]),
+    "frcnn_topk_desc_nchw_supported": (_I, [_I, _I, _I, _I]),
+    "frcnn_topk_desc_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _I, _P]),
+    "frcnn_decode_clip_filter_nchw_f32": (_I, [_P, _L, _P, _P, _I, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P,
+                                               _P]),
     "frcnn_nms_workspace_bytes": (_Z, [_I, _I]),
     "frcnn_nms_sorted_f32": (_I, [_P, _P, _I, _I, _D, _I, _P, _P, _P, _Z, _P]),
     "frcnn_gather_boxes_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),

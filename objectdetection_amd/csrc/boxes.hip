@@ -314,6 +314,42 @@ decode_clip_filter_kernel(const float4 *__restrict__ anchors, long long anchor_b
     if (gridDim.x == 1 && threadIdx.x == 0) count_out[b] = tot;
 }
 
+// the same with the deltas read from the head's NCHW outputs (common.h: RpnLevels)
+__global__ void __launch_bounds__(1024)
+decode_clip_filter_nchw_kernel(const float4 *__restrict__ anchors, long long anchor_batch_stride4, RpnLevels L,
+                               const int32_t *__restrict__ top_idx, const float *__restrict__ top_score, int k,
+                               float image_h, float image_w, float min_size, float4 *__restrict__ boxes_out,
+                               float *__restrict__ scores_out, int32_t *__restrict__ src_out,
+                               int32_t *__restrict__ count_out)
+{
+    __shared__ int wave_sums[16];
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;
+    const float4 *anc = anchors + (long long)b * anchor_batch_stride4;
+    float4 *bo = boxes_out + (long long)b * k + tile * 1024;
+    float *so = scores_out + (long long)b * k + tile * 1024;
+    int32_t *ro = src_out + (long long)b * k + tile * 1024;
+    const int i = tile * 1024 + threadIdx.x;
+    bool keep = false;
+    float4 p = make_float4(0, 0, 0, 0);
+    float s = 0.0f;
+    if (i < k) {
+        s = top_score[(long long)b * k + i];
+        const int a = top_idx[(long long)b * k + i];
+        p = clip_box(decode_one(anc[a], rpn_delta(L, b, a), (float)FRCNN_DW_CLAMP), image_h, image_w);
+        keep = (p.z - p.x > min_size) && (p.w - p.y > min_size);
+    }
+    int tot;
+    const int pos = frcnn_block_excl_count(keep, wave_sums, &tot);
+    if (keep) {
+        bo[pos] = p;
+        so[pos] = s;
+        ro[pos] = i;
+    }
+    if ((int)threadIdx.x >= tot && i < k) ro[threadIdx.x] = -1;
+    if (gridDim.x == 1 && threadIdx.x == 0) count_out[b] = tot;
+}
+
 __global__ void __launch_bounds__(1024)
 decode_close_gaps_kernel(int k, float4 *__restrict__ boxes_out, float *__restrict__ scores_out,
                          int32_t *__restrict__ src_out, int32_t *__restrict__ count_out)
@@ -392,6 +428,34 @@ extern "C" int frcnn_decode_clip_filter_f32(const float *anchors, int64_t anchor
                        (const float4 *)deltas, top_idx, top_score, A, k, image_h, image_w, min_size,
                        (float4 *)boxes_out, scores_out, src_out, count_out);
     FRCNN_CHECK_LAUNCH("decode_clip_filter");
+    if (tiles > 1) {
+        hipLaunchKernelGGL(decode_close_gaps_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, k,
+                           (float4 *)boxes_out, scores_out, src_out, count_out);
+        FRCNN_CHECK_LAUNCH("decode_close_gaps");
+    }
+    return FRCNN_OK;
+}
+
+extern "C" int frcnn_decode_clip_filter_nchw_f32(const float *anchors, int64_t anchor_batch_stride,
+                                                 const float *const *reg_host, const int32_t *hw_host, int n_levels,
+                                                 int na, const int32_t *top_idx, const float *top_score, int B, int k,
+                                                 float image_h, float image_w, float min_size, float *boxes_out,
+                                                 float *scores_out, int32_t *src_out, int32_t *count_out,
+                                                 void *stream)
+{
+    FRCNN_REQUIRE(B > 0 && B <= 65535 && k > 0 && reg_host, "decode_clip_filter_nchw: bad shape");
+    RpnLevels L;
+    const long long A = frcnn_make_levels(&L, nullptr, reg_host, hw_host, n_levels, na);
+    FRCNN_REQUIRE(A > 0 && k <= A, "decode_clip_filter_nchw: bad level table or k > A");
+    for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(reg_host[l], "decode_clip_filter_nchw: null level %d", l);
+    FRCNN_REQUIRE(anchors && top_idx && top_score && boxes_out && scores_out && src_out && count_out,
+                  "decode_clip_filter_nchw: null pointer");
+    FRCNN_REQUIRE(anchor_batch_stride % 4 == 0, "decode_clip_filter_nchw: anchor stride not a box multiple");
+    const int tiles = (k + 1023) / 1024;
+    hipLaunchKernelGGL(decode_clip_filter_nchw_kernel, dim3(tiles, B), dim3(1024), 0, (hipStream_t)stream,
+                       (const float4 *)anchors, (long long)(anchor_batch_stride / 4), L, top_idx, top_score, k, image_h,
+                       image_w, min_size, (float4 *)boxes_out, scores_out, src_out, count_out);
+    FRCNN_CHECK_LAUNCH("decode_clip_filter_nchw");
     if (tiles > 1) {
         hipLaunchKernelGGL(decode_close_gaps_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, k,
                            (float4 *)boxes_out, scores_out, src_out, count_out);

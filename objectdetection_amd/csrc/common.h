@@ -154,3 +154,78 @@ __device__ __forceinline__ int frcnn_block_excl_count(bool flag, int *wave_sums,
     *total = tot;
     return base + in_wave;
 }
+
+// ---- the RPN head's outputs read in place ------------------------------------------------------------
+// RPN/rpn.py:56-57 flattens the per-level (B, na, h, w) scores and (B, 4 na, h, w) deltas to one vector per
+// image, flat index e = level offset + cell * na + a.  Kernels that take a level table read element e
+// where it lies instead of from a flattened copy.  The table travels by value (kernel argument); the level
+// of e is found by compare-and-select over statically indexed entries so that it stays in scalar
+// registers.  Unused levels start at A, so no index selects them.
+#define FRCNN_MAX_LEVELS 6
+struct RpnLevels {
+    const float *cls[FRCNN_MAX_LEVELS]; // (B, na, h, w)
+    const float *reg[FRCNN_MAX_LEVELS]; // (B, 4 na, h, w)
+    int hw[FRCNN_MAX_LEVELS];
+    int off[FRCNN_MAX_LEVELS]; // first flat index of each level (A for unused levels)
+    int na;
+};
+
+struct RpnElem { // where flat element e lives
+    const float *cls, *reg;
+    int hw, a, cell;
+};
+
+__device__ __forceinline__ RpnElem rpn_locate(const RpnLevels &L, int e)
+{
+    RpnElem r;
+    r.cls = L.cls[0];
+    r.reg = L.reg[0];
+    r.hw = L.hw[0];
+    int off = 0;
+#pragma unroll
+    for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) {
+        const bool in = e >= L.off[l];
+        r.cls = in ? L.cls[l] : r.cls;
+        r.reg = in ? L.reg[l] : r.reg;
+        r.hw = in ? L.hw[l] : r.hw;
+        off = in ? L.off[l] : off;
+    }
+    const int rem = e - off;
+    r.cell = rem / L.na;
+    r.a = rem - r.cell * L.na;
+    return r;
+}
+
+__device__ __forceinline__ float rpn_score(const RpnLevels &L, int b, int e)
+{
+    const RpnElem r = rpn_locate(L, e);
+    return r.cls[((long long)b * L.na + r.a) * r.hw + r.cell];
+}
+
+__device__ __forceinline__ float4 rpn_delta(const RpnLevels &L, int b, int e)
+{
+    const RpnElem r = rpn_locate(L, e);
+    const float *p = r.reg + ((long long)b * 4 * L.na + 4 * r.a) * r.hw + r.cell;
+    return make_float4(p[0], p[r.hw], p[2 * r.hw], p[3 * r.hw]);
+}
+
+// Fills a table from host arrays of per-level device pointers and (h, w) pairs; returns A or -1.
+static inline long long frcnn_make_levels(RpnLevels *L, const float *const *cls_host, const float *const *reg_host,
+                                          const int32_t *hw_host, int n_levels, int na)
+{
+    if (n_levels <= 0 || n_levels > FRCNN_MAX_LEVELS || na <= 0 || !hw_host) return -1;
+    long long A = 0;
+    L->na = na;
+    for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+        const bool used = l < n_levels;
+        if (used && (hw_host[2 * l] <= 0 || hw_host[2 * l + 1] <= 0)) return -1;
+        L->cls[l] = used && cls_host ? cls_host[l] : nullptr;
+        L->reg[l] = used && reg_host ? reg_host[l] : nullptr;
+        L->hw[l] = used ? hw_host[2 * l] * hw_host[2 * l + 1] : 0;
+        L->off[l] = (int)A;
+        if (used) A += (long long)L->hw[l] * na;
+        if (A >= (1ll << 31)) return -1;
+    }
+    for (int l = n_levels; l < FRCNN_MAX_LEVELS; ++l) L->off[l] = (int)A;
+    return A;
+}

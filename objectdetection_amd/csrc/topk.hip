@@ -554,8 +554,19 @@ __device__ __forceinline__ unsigned long long wave_match11(unsigned digit, bool 
 
 // sc: the n scores to sort; the first k positions of the result go to idx_out[0..k) (index into sc) and,
 // when val_out is given, val_out[0..k) (the score, or its raw sort key when RAWKEY); ws: 4 n words.
-template <int KR, bool RAWKEY>
-__device__ __forceinline__ void topk_sort_body(const float *__restrict__ sc, int n, int k, uint32_t *__restrict__ val_out,
+// Where the keys of pass 0 come from: scores in a flat array, or keys made beforehand.
+struct FlatScores {
+    const float *sc;
+    __device__ __forceinline__ uint32_t key(int e) const { return frcnn_score_key(sc[e]); }
+};
+
+struct ReadyKeys {
+    const uint32_t *keys;
+    __device__ __forceinline__ uint32_t key(int e) const { return keys[e]; }
+};
+
+template <int KR, bool RAWKEY, typename Src>
+__device__ __forceinline__ void topk_sort_body(const Src src, int n, int k, uint32_t *__restrict__ val_out,
                                                int32_t *__restrict__ idx_out, uint32_t *__restrict__ ws)
 {
     __shared__ unsigned s_cnt[TOPK_WAVES][TOPK_SORT_BINS];
@@ -584,7 +595,7 @@ __device__ __forceinline__ void topk_sort_body(const float *__restrict__ sc, int
             const int e = seg_lo + r * 64 + lane;
             const bool act = e < seg_hi;
             if (pass == 0) {
-                kreg[r] = act ? frcnn_score_key(sc[e]) : 0u;
+                kreg[r] = act ? src.key(e) : 0u;
                 ireg[r] = (unsigned)e;
             } else {
                 kreg[r] = act ? kin[e] : 0u;
@@ -671,8 +682,9 @@ topk_sort_kernel(const float *__restrict__ scores, int n, int k, float *__restri
                  int32_t *__restrict__ idx_out, uint32_t *__restrict__ ws)
 {
     const long long b = blockIdx.x;
-    topk_sort_body<KR, false>(scores + b * n, n, k, val_out ? (uint32_t *)val_out + b * k : nullptr, idx_out + b * k,
-                              ws + b * 4 * n);
+    FlatScores src;
+    src.sc = scores + b * n;
+    topk_sort_body<KR, false>(src, n, k, val_out ? (uint32_t *)val_out + b * k : nullptr, idx_out + b * k, ws + b * 4 * n);
 }
 
 // ---- split variant: several workgroups per image ---------------------------------------------------
@@ -703,8 +715,31 @@ topk_slice_sort_kernel(const float *__restrict__ scores, int n, int k, int S, in
     const int start = s * slice_len;
     const int n_s = min(slice_len, n - start);
     const long long list = (b * S + s) * kcap;
-    topk_sort_body<KR, true>(scores + b * n + start, n_s, min(k, n_s), skeys + list, sidx + list,
-                             ws + b * 4 * n + 4ll * start);
+    FlatScores src;
+    src.sc = scores + b * n + start;
+    topk_sort_body<KR, true>(src, n_s, min(k, n_s), skeys + list, sidx + list, ws + b * 4 * n + 4ll * start);
+}
+
+// The same on the RPN head's outputs where they lie (common.h: RpnLevels): the slice's keys are made
+// first, in flat order, into the one buffer of its workspace that the sort's first pass does not write --
+// the level lookup stays out of the sort's unrolled, register-resident loops.
+template <int KR>
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_slice_sort_nchw_kernel(RpnLevels L, int n, int k, int S, int slice_len, int kcap, uint32_t *__restrict__ ws,
+                            uint32_t *__restrict__ skeys, int32_t *__restrict__ sidx)
+{
+    const long long b = blockIdx.x / S;
+    const int s = blockIdx.x % S;
+    const int start = s * slice_len;
+    const int n_s = min(slice_len, n - start);
+    const long long list = (b * S + s) * kcap;
+    uint32_t *wss = ws + b * 4 * n + 4ll * start;
+#pragma unroll 4
+    for (int e = threadIdx.x; e < n_s; e += TOPK_THREADS) wss[e] = frcnn_score_key(rpn_score(L, (int)b, start + e));
+    __syncthreads();
+    ReadyKeys src;
+    src.keys = wss;
+    topk_sort_body<KR, true>(src, n_s, min(k, n_s), skeys + list, sidx + list, wss);
 }
 
 // number of leading elements of a descending list that go before key K: those >= K (or_equal) or > K
@@ -903,11 +938,41 @@ extern "C" size_t frcnn_topk_workspace_bytes(int B, int n, int k)
 }
 
 template <int KR>
-static void topk_launch_slices(const float *scores, int B, int n, int k, const TopkSplit &sp, uint32_t *ws,
-                               uint32_t *skeys, int32_t *sidx, hipStream_t stream)
+static void topk_launch_slices(const float *scores, const RpnLevels *levels, int B, int n, int k, const TopkSplit &sp,
+                               uint32_t *ws, uint32_t *skeys, int32_t *sidx, hipStream_t stream)
 {
-    hipLaunchKernelGGL((topk_slice_sort_kernel<KR>), dim3(B * sp.S), dim3(TOPK_THREADS), 0, stream, scores, n, k, sp.S,
-                       sp.slice_len, sp.kcap, ws, skeys, sidx);
+    if (levels)
+        hipLaunchKernelGGL((topk_slice_sort_nchw_kernel<KR>), dim3(B * sp.S), dim3(TOPK_THREADS), 0, stream, *levels, n,
+                           k, sp.S, sp.slice_len, sp.kcap, ws, skeys, sidx);
+    else
+        hipLaunchKernelGGL((topk_slice_sort_kernel<KR>), dim3(B * sp.S), dim3(TOPK_THREADS), 0, stream, scores, n, k,
+                           sp.S, sp.slice_len, sp.kcap, ws, skeys, sidx);
+}
+
+// slice sorts + merge; scores == nullptr: read the level table instead
+static int topk_run_split(const float *scores, const RpnLevels *levels, int B, int n, int k, const TopkSplit &sp,
+                          float *val_out, int32_t *idx_out, void *workspace, hipStream_t stream)
+{
+    uint32_t *ws = (uint32_t *)workspace;
+    uint32_t *skeys = ws + (size_t)B * 4 * n;
+    int32_t *sidx = (int32_t *)(skeys + (size_t)B * sp.S * sp.kcap);
+    const int rounds = (sp.slice_len + TOPK_THREADS - 1) / TOPK_THREADS;
+    if (rounds <= 2)
+        topk_launch_slices<2>(scores, levels, B, n, k, sp, ws, skeys, sidx, stream);
+    else if (rounds <= 4)
+        topk_launch_slices<4>(scores, levels, B, n, k, sp, ws, skeys, sidx, stream);
+    else if (rounds <= 8)
+        topk_launch_slices<8>(scores, levels, B, n, k, sp, ws, skeys, sidx, stream);
+    else if (rounds <= 13)
+        topk_launch_slices<13>(scores, levels, B, n, k, sp, ws, skeys, sidx, stream);
+    else
+        topk_launch_slices<TOPK_SORT_KR>(scores, levels, B, n, k, sp, ws, skeys, sidx, stream);
+    FRCNN_CHECK_LAUNCH("topk_slice_sort");
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((sp.kcap + TOPK_MERGE_THREADS - 1) / TOPK_MERGE_THREADS, sp.S, B),
+                       dim3(TOPK_MERGE_THREADS), 0, stream, skeys, sidx, n, k, sp.S, sp.slice_len, sp.kcap, val_out,
+                       idx_out);
+    FRCNN_CHECK_LAUNCH("topk_merge");
+    return FRCNN_OK;
 }
 
 extern "C" int frcnn_topk_desc_ex_f32(const float *scores, int B, int n, int k, float *val_out, int32_t *idx_out,
@@ -932,29 +997,8 @@ extern "C" int frcnn_topk_desc_ex_f32(const float *scores, int B, int n, int k, 
         return FRCNN_EWORKSPACE;
     }
     TopkSplit sp;
-    if (topk_split_plan(B, n, k, max_slices, &sp)) {
-        uint32_t *ws = (uint32_t *)workspace;
-        uint32_t *skeys = ws + (size_t)B * 4 * n;
-        int32_t *sidx = (int32_t *)(skeys + (size_t)B * sp.S * sp.kcap);
-        const int rounds = (sp.slice_len + TOPK_THREADS - 1) / TOPK_THREADS;
-        if (rounds <= 2)
-            topk_launch_slices<2>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
-        else if (rounds <= 4)
-            topk_launch_slices<4>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
-        else if (rounds <= 8)
-            topk_launch_slices<8>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
-        else if (rounds <= 13)
-            topk_launch_slices<13>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
-        else
-            topk_launch_slices<TOPK_SORT_KR>(scores, B, n, k, sp, ws, skeys, sidx, (hipStream_t)stream);
-        FRCNN_CHECK_LAUNCH("topk_slice_sort");
-        hipLaunchKernelGGL(topk_merge_kernel,
-                           dim3((sp.kcap + TOPK_MERGE_THREADS - 1) / TOPK_MERGE_THREADS, sp.S, B),
-                           dim3(TOPK_MERGE_THREADS), 0, (hipStream_t)stream, skeys, sidx, n, k, sp.S, sp.slice_len,
-                           sp.kcap, val_out, idx_out);
-        FRCNN_CHECK_LAUNCH("topk_merge");
-        return FRCNN_OK;
-    }
+    if (topk_split_plan(B, n, k, max_slices, &sp))
+        return topk_run_split(scores, nullptr, B, n, k, sp, val_out, idx_out, workspace, (hipStream_t)stream);
     if (topk_use_sort(n, k))
         hipLaunchKernelGGL((topk_sort_kernel<TOPK_SORT_KR>), dim3(B), dim3(TOPK_THREADS), 0, (hipStream_t)stream,
                            scores, n, k, val_out, idx_out, (uint32_t *)workspace);
@@ -972,4 +1016,32 @@ extern "C" int frcnn_topk_desc_ex_f32(const float *scores, int B, int n, int k, 
                            k, val_out, idx_out, (uint32_t *)workspace);
     FRCNN_CHECK_LAUNCH("topk");
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_topk_desc_nchw_supported(int B, int A, int k, int max_slices)
+{
+    TopkSplit sp;
+    return (B > 0 && k > 0 && k <= A && topk_split_plan(B, A, k, max_slices, &sp)) ? 1 : 0;
+}
+
+extern "C" int frcnn_topk_desc_nchw_f32(const float *const *cls_host, const int32_t *hw_host, int n_levels, int na,
+                                        int B, int k, float *val_out, int32_t *idx_out, void *workspace,
+                                        size_t workspace_bytes, int max_slices, void *stream)
+{
+    FRCNN_REQUIRE(cls_host && B > 0 && k > 0, "topk_nchw: bad arguments");
+    RpnLevels L;
+    const long long A = frcnn_make_levels(&L, cls_host, nullptr, hw_host, n_levels, na);
+    FRCNN_REQUIRE(A > 0, "topk_nchw: bad level table (1..%d levels, positive sizes)", FRCNN_MAX_LEVELS);
+    for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(cls_host[l], "topk_nchw: null level %d", l);
+    FRCNN_REQUIRE(k <= A, "topk_nchw: k (%d) > A (%lld)", k, A);
+    TopkSplit sp;
+    FRCNN_REQUIRE(topk_split_plan(B, (int)A, k, max_slices, &sp),
+                  "topk_nchw: A=%lld is outside the split path's range (flatten and use frcnn_topk_desc_f32)", A);
+    FRCNN_REQUIRE(idx_out && workspace, "topk_nchw: null pointer");
+    if (workspace_bytes < frcnn_topk_workspace_bytes(B, (int)A, k)) {
+        frcnn_set_error("topk_nchw: workspace too small (%zu < %zu)", workspace_bytes,
+                        frcnn_topk_workspace_bytes(B, (int)A, k));
+        return FRCNN_EWORKSPACE;
+    }
+    return topk_run_split(nullptr, &L, B, (int)A, k, sp, val_out, idx_out, workspace, (hipStream_t)stream);
 }

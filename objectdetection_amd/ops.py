@@ -116,6 +116,83 @@ def topk_desc(scores, k, want_values=True, max_slices=0):
     return vals, idx
 
 
+def _level_table(tensors, na, per_cell):
+    """Host arrays for the C ABI's level tables: device pointers and (h, w) of every level."""
+    ts = []
+    hw = []
+    for t in tensors:
+        if t.shape[1] != per_cell * na:
+            raise ValueError("rpn head output %s does not have %d channels" % (tuple(t.shape), per_cell * na))
+        ts.append(_f32c(t))
+        hw += [t.shape[2], t.shape[3]]
+    ptrs = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    hw_arr = (ctypes.c_int32 * len(hw))(*hw)
+    return ts, ptrs, hw_arr
+
+
+def rpn_in_place_supported(list_cls, k, max_slices=0):
+    """True where topk_desc_nchw / decode_clip_filter_nchw cover the head outputs (else: rpn_flatten first)."""
+    if len(list_cls) > 6:
+        return False
+    B, na = list_cls[0].shape[0], list_cls[0].shape[1]
+    A = sum(c.shape[1] * c.shape[2] * c.shape[3] for c in list_cls)
+    return bool(_lib.load().frcnn_topk_desc_nchw_supported(B, A, int(k), int(max_slices)))
+
+
+def topk_desc_nchw(list_cls, k, want_values=True, max_slices=0):
+    """topk_desc over the flattened scores of RPN/rpn.py:56, read from the (B,na,h,w) head outputs in place."""
+    _need_gpu(*list_cls)
+    B, na = list_cls[0].shape[0], list_cls[0].shape[1]
+    ts, ptrs, hw = _level_table(list_cls, na, 1)
+    A = na * sum(hw[2 * i] * hw[2 * i + 1] for i in range(len(ts)))
+    dev = ts[0].device
+    vals = torch.empty((B, k), dtype=torch.float32, device=dev) if want_values else None
+    idx = torch.empty((B, k), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.frcnn_topk_workspace_bytes(B, A, k)
+    ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.frcnn_topk_desc_nchw_f32(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p),
+                                          len(ts), na, B, k, _ptr(vals), _ptr(idx), _ptr(ws), nbytes, int(max_slices),
+                                          _stream())
+    _lib.check(rc, "topk_desc_nchw")
+    return vals, idx
+
+
+def decode_clip_filter_nchw(anchors, list_regs, top_idx, top_score, image_h, image_w, min_size):
+    """decode_clip_filter with the deltas read from the (B,4na,h,w) head outputs in place."""
+    _need_gpu(anchors, top_idx, top_score, *list_regs)
+    B = list_regs[0].shape[0]
+    na = list_regs[0].shape[1] // 4
+    ts, ptrs, hw = _level_table(list_regs, na, 4)
+    A = na * sum(hw[2 * i] * hw[2 * i + 1] for i in range(len(ts)))
+    anchors, top_score = _f32c(anchors), _f32c(top_score)
+    top_idx = top_idx.contiguous()
+    if top_idx.dtype != torch.int32:
+        top_idx = top_idx.to(torch.int32)
+    k = top_idx.shape[1]
+    if anchors.dim() == 2:
+        stride = 0
+        if anchors.shape[0] != A:
+            raise ValueError("anchors (%d) and head outputs (%d) disagree" % (anchors.shape[0], A))
+    else:
+        stride = A * 4
+        if anchors.shape[0] != B or anchors.shape[1] != A:
+            raise ValueError("anchors %s vs head outputs (B=%d, A=%d)" % (tuple(anchors.shape), B, A))
+    dev = ts[0].device
+    boxes = torch.empty((B, k, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, k), dtype=torch.float32, device=dev)
+    src = torch.empty((B, k), dtype=torch.int32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().frcnn_decode_clip_filter_nchw_f32(
+            _ptr(anchors), stride, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p), len(ts), na,
+            _ptr(top_idx), _ptr(top_score), B, k, float(image_h), float(image_w), float(min_size), _ptr(boxes),
+            _ptr(scores), _ptr(src), _ptr(count), _stream())
+    _lib.check(rc, "decode_clip_filter_nchw")
+    return boxes, scores, src, count
+
+
 # ------------------------------------------------------------------ K3 decode / clip / filter
 def box_regression(box, regs):
     _need_gpu(box, regs)

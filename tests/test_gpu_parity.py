@@ -344,6 +344,58 @@ def test_decode_clip_filter_gaps(dev, B, A, k, min_size):
         assert ((cnt > 0) & (cnt < k)).all()
 
 
+@pytest.mark.parametrize("levels,na,B,k,per_image_anchors,min_size", [
+    ([(37, 62)], 9, 4, 12000, False, 1e-3),                                      # the headline shape
+    ([(37, 62)], 9, 2, 20646, False, 2.0),                                       # k = A
+    ([(50, 76), (25, 38), (13, 19), (7, 10)], 3, 3, 9000, True, 2.0),            # A = 15201 over four levels
+    ([(64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (2, 2)], 2, 2, 6000, False, 2.0),   # six levels
+    ([(100, 168), (50, 84), (25, 42), (13, 21)], 9, 2, 30000, False, 1e-3),      # config 5: A = 200,907
+])
+def test_rpn_in_place_matches_flattened(dev, levels, na, B, k, per_image_anchors, min_size):
+    """Top-k and decode reading the head's NCHW outputs in place return the same bits as rpn_flatten +
+    topk_desc + decode_clip_filter: ties, +-inf and filtered rows included."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(k + na)
+    list_cls, list_regs = [], []
+    for (h, w) in levels:
+        c = rng.standard_normal((B, na, h, w)).astype(np.float32)
+        c = np.round(c * 64) / 64            # many exact ties: order must fall back to the flat index
+        c[:, :, ::5, ::7] = np.float32(0.25)
+        c[0, 0, 0, 0] = np.inf
+        c[-1, -1, -1, -1] = -np.inf
+        list_cls.append(T(c, dev))
+        list_regs.append(T((rng.standard_normal((B, 4 * na, h, w)) * 0.5).astype(np.float32), dev))
+    A = na * sum(h * w for h, w in levels)
+    assert ops.rpn_in_place_supported(list_cls, k)
+    assert not ops.rpn_in_place_supported(list_cls, k, max_slices=1) or A > 21504
+    anc = realistic_boxes(rng, A if not per_image_anchors else B * A)
+    anc[::9, 2:] = anc[::9, :2] + 0.5        # tiny anchors: some decoded boxes fall under min_size
+    anchors = T(anc.reshape(B, A, 4) if per_image_anchors else anc, dev)
+    scores, deltas = ops.rpn_flatten(list_cls, list_regs)
+    tv, ti = ops.topk_desc(scores, k)
+    b0, s0, r0, c0 = ops.decode_clip_filter(anchors, deltas, ti, tv, 600.0, 1000.0, min_size)
+    tv1, ti1 = ops.topk_desc_nchw(list_cls, k)
+    b1, s1, r1, c1 = ops.decode_clip_filter_nchw(anchors, list_regs, ti1, tv1, 600.0, 1000.0, min_size)
+    assert torch.equal(ti, ti1)
+    assert_bits_equal(tv.cpu().numpy(), tv1.cpu().numpy())
+    assert torch.equal(c0, c1)
+    cnt = c0.cpu().numpy()
+    assert (cnt > 0).all()
+    for b in range(B):
+        n = int(cnt[b])
+        assert torch.equal(r0[b, :n], r1[b, :n])
+        assert_bits_equal(b0[b, :n].cpu().numpy(), b1[b, :n].cpu().numpy())
+        assert_bits_equal(s0[b, :n].cpu().numpy(), s1[b, :n].cpu().numpy())
+
+
+def test_rpn_in_place_rejects_small_images(dev):
+    from objectdetection_amd import ops
+    cls = torch.zeros((1, 3, 20, 20), device=dev)
+    assert not ops.rpn_in_place_supported([cls], 1000)
+    with pytest.raises(RuntimeError, match="outside the split path's range"):
+        ops.topk_desc_nchw([cls], 1000)
+
+
 # ---------------------------------------------------------------------------------- NMS (K4)
 def lattice_boxes(n):
     side = int(np.ceil(np.sqrt(n)))
