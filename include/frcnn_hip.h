@@ -247,6 +247,12 @@ int frcnn_roi_loss_f32(const float *logits, const float *pred, const float *cls_
 int frcnn_resize_pad_f32(const float *src, int C, int in_h, int in_w, int out_h, int out_w,
                          float *dst, int canvas_h, int canvas_w, void *stream);
 
+/* The same for a whole batch in one launch (per 32 images): src_host is a HOST array of n device pointers to
+ * (C,in_h,in_w) images, shape_host a HOST array (n,4) of (in_h, in_w, out_h, out_w); dst is the
+ * (n, C, canvas_h, canvas_w) batch.  Bit-identical to n calls of frcnn_resize_pad_f32. */
+int frcnn_resize_pad_batch_f32(const float *const *src_host, const int32_t *shape_host, int n, int C,
+                               float *dst, int canvas_h, int canvas_w, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

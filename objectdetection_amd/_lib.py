@@ -51,6 +51,7 @@ SIGNATURES = {
     "frcnn_rpn_sampled_loss_f32": (_I, [_P, _P, _P, _P, _P, _I, _L, _F, _P, _P, _P, _P]),
     "frcnn_roi_loss_f32": (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
     "frcnn_resize_pad_f32": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "frcnn_resize_pad_batch_f32": (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
 }
 
 

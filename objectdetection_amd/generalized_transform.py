@@ -43,8 +43,7 @@ def _assemble(images, out_sizes, divide_size):
             raise ValueError("a (%d, %d, %d) image does not fit the (%d, %d, %d) canvas the reference computes "
                              "(utils.py:353-357: the elif skips widths)" % (im.size(0), h, w, channels, canvas_h, canvas_w))
     batch = torch.empty((len(images), channels, canvas_h, canvas_w), dtype=torch.float32, device=images[0].device)
-    for i, (im, (h, w)) in enumerate(zip(images, out_sizes)):
-        ops.resize_pad_into(im, h, w, batch[i])
+    ops.resize_pad_batch(images, out_sizes, batch)   # one launch for the list (per 32 images)
     return batch
 
 

@@ -260,6 +260,28 @@ def resize_pad_into(image, out_h, out_w, canvas):
     return canvas
 
 
+def resize_pad_batch(images, out_sizes, batch):
+    """resize_pad_into for every image of a list in ONE launch: images[i] (C,h_i,w_i) -> batch[i] (C,H,W)."""
+    _need_gpu(batch, *images)
+    imgs = [_f32c(im) for im in images]
+    n = len(imgs)
+    if batch.dim() != 4 or batch.shape[0] != n or not batch.is_contiguous() or batch.dtype != torch.float32:
+        raise ValueError("resize_pad_batch expects a contiguous fp32 batch (n,C,H,W)")
+    C = batch.shape[1]
+    shapes = []
+    for im, (oh, ow) in zip(imgs, out_sizes):
+        if im.dim() != 3 or im.shape[0] != C:
+            raise ValueError("resize_pad_batch: image %s vs %d channels" % (tuple(im.shape), C))
+        shapes += [im.shape[1], im.shape[2], int(oh), int(ow)]
+    ptrs = (ctypes.c_void_p * n)(*[im.data_ptr() for im in imgs])
+    sh = (ctypes.c_int32 * (4 * n))(*shapes)
+    with torch.cuda.device(batch.device):
+        rc = _lib.load().frcnn_resize_pad_batch_f32(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(sh, ctypes.c_void_p),
+                                                    n, C, _ptr(batch), batch.shape[2], batch.shape[3], _stream())
+    _lib.check(rc, "resize_pad_batch")
+    return batch
+
+
 def roi_detect_filter(props, regs, scores, row_off, image_sizes, max_rows, score_thresh, min_size):
     """ROIHead/roi_head.py:178-209 for a batch: props (N,4) concatenated, regs (N,K,4) or (N,4K), scores (N,K),
     row_off (B+1) int32, image_sizes (B,2) fp32 (h,w).  -> boxes (B,M,4), scores (B,M), labels (B,M) int32,
