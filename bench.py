@@ -451,7 +451,7 @@ def next_rows_microbench(dev):
     ms = timed(lambda: gt(list(images), [None] * B))
     nbytes = B * 3 * (IMG_H * IMG_W + 608 * 1024) * 4
     res["batch_assembly"] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / ms / 1e6,
-                             "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "launches": B}
+                             "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "launches": (B + 31) // 32}
     # row 2: RPN loss tail, 256 sampled anchors per image out of A; forward + gradients in one launch (+2 memsets)
     scores = torch.randn(B, A, generator=g).to(dev)
     regs = torch.randn(B, A, 4, generator=g).to(dev)
