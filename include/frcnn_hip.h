@@ -211,7 +211,8 @@ int frcnn_roi_pool_f32(const float *feat, int B, int C, int H, int W, const floa
  * fp32 device (h, w).  Candidate (j, c) of an image is decoded (box_regression), clipped to that
  * image's size and kept when score > score_thresh, w > min_size, h > min_size and c > 0, in the
  * reference's flat order j*K + c.  Outputs are (B, max_rows*K[,4]) with the first count_out[b]
- * rows of each image valid: boxes, scores, labels (int32 class ids). */
+ * rows of each image valid: boxes, scores, labels (int32 class ids); rows beyond the count are
+ * unspecified (labels_out's are used as scratch between the two launches). */
 int frcnn_roi_detect_filter_f32(const float *props, const float *regs, const float *scores,
                                 const int32_t *row_off, const float *image_sizes, int B, int K,
                                 int max_rows, float score_thresh, float min_size, float *boxes_out,

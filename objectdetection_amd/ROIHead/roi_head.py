@@ -128,11 +128,20 @@ class ROIHead(Module):
                 sorted_boxes = ops.gather_boxes(boxes, order, count)
                 keep, n_keep = ops.nms_sorted(sorted_boxes, count, self.nms_threshold, self.num_post_nms)
                 n_kept = n_keep.tolist()                              # host read 2: detections per image
+                # four batched gathers; the per-image lists are views of their results (keep rows beyond
+                # n_keep are unspecified: clamped, then cut off by the views)
+                top = max(max(n_kept), 1)
+                index = torch.gather(order, 1, keep[:, :top].clamp(0, vmax - 1).long()).long()
+                det_boxes = torch.gather(boxes, 1, index[:, :, None].expand(-1, -1, 4))
+                det_scores = torch.gather(scores, 1, index)
+                det_labels = torch.gather(labels, 1, index).long()
             for i in range(B):
-                if vmax > 0 and n_kept[i] > 0:
-                    index = order[i, keep[i, :n_kept[i]].long()].long()
+                n = n_kept[i] if vmax > 0 else 0
+                if n > 0:
+                    result.append({'proposal': det_boxes[i, :n], 'score': det_scores[i, :n],
+                                   'label': det_labels[i, :n]})
                 else:
-                    index = torch.empty((0,), dtype=torch.int64, device=device)
-                result.append({'proposal': boxes[i, index], 'score': scores[i, index],
-                               'label': labels[i, index].long()})
+                    result.append({'proposal': torch.empty((0, 4), dtype=torch.float32, device=device),
+                                   'score': torch.empty((0,), dtype=torch.float32, device=device),
+                                   'label': torch.empty((0,), dtype=torch.int64, device=device)})
         return result, roi_loss

@@ -470,9 +470,7 @@ extern "C" int frcnn_decode_clip_filter_nchw_f32(const float *anchors, int64_t a
 // size, and keep it when score > score_thresh (:197), w > min_size and h > min_size (:203) and c > 0
 // (:209).  The three filters of the reference are order-preserving and each looks at one candidate
 // only, so applying them as one predicate gives the same list.  Workgroup = (tile of 1024
-// candidates, image); a tile re-derives the keep count of the tiles
-// before it -- cheaply, because almost every candidate already fails the score test, which needs no
-// decode.
+// candidates, image).  Fallback kernel (K > 1024): a tile re-derives the keep count of the tiles before it.
 __device__ __forceinline__ bool detect_keep(const float4 *__restrict__ props, const float4 *__restrict__ regs,
                                             const float *__restrict__ scores, long long row0, int m, int K,
                                             float image_h, float image_w, float score_thresh, float min_size,
@@ -489,7 +487,7 @@ __device__ __forceinline__ bool detect_keep(const float4 *__restrict__ props, co
 }
 
 __global__ void __launch_bounds__(1024)
-roi_detect_filter_kernel(const float4 *__restrict__ props, const float4 *__restrict__ regs,
+roi_detect_filter_rederive_kernel(const float4 *__restrict__ props, const float4 *__restrict__ regs,
                          const float *__restrict__ scores, const int32_t *__restrict__ row_off,
                          const float *__restrict__ image_sizes, int K, float score_thresh, float min_size,
                          int cap, float4 *__restrict__ boxes_out, float *__restrict__ scores_out,
@@ -530,6 +528,70 @@ roi_detect_filter_kernel(const float4 *__restrict__ props, const float4 *__restr
     if (threadIdx.x == 0 && (tile + 1) * 1024 >= M) count_out[b] = base + tot; // the image's last tile
 }
 
+// Two launches for K <= 1024 classes.  Class 0 is never kept, so an image with r rows keeps at most r (K - 1)
+// of its M = r K candidates: slots [M - r, M) of its labels_out row are never an output row, and an image has
+// at most r tiles of 1024 candidates when K <= 1024.  The first launch leaves every tile's keep count in slot
+// M - 1 - tile; the second adds up the counts of the tiles before its own instead of re-deriving them.
+__global__ void __launch_bounds__(1024)
+roi_detect_count_kernel(const float4 *__restrict__ props, const float4 *__restrict__ regs,
+                        const float *__restrict__ scores, const int32_t *__restrict__ row_off,
+                        const float *__restrict__ image_sizes, int K, float score_thresh, float min_size, int cap,
+                        int32_t *__restrict__ labels_out)
+{
+    __shared__ int wave_sums[16];
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;
+    const long long row0 = row_off[b];
+    const int M = (row_off[b + 1] - row_off[b]) * K;
+    if (tile * 1024 >= M) return;
+    const float image_h = image_sizes[2 * b], image_w = image_sizes[2 * b + 1];
+    const int m = tile * 1024 + threadIdx.x;
+    float4 p;
+    float sc;
+    const bool keep = m < M && detect_keep(props, regs, scores, row0, m, K, image_h, image_w, score_thresh,
+                                           min_size, &p, &sc);
+    int tot;
+    frcnn_block_excl_count(keep, wave_sums, &tot);
+    if (threadIdx.x == 0) labels_out[(long long)b * cap + M - 1 - tile] = tot;
+}
+
+__global__ void __launch_bounds__(1024)
+roi_detect_filter_kernel(const float4 *__restrict__ props, const float4 *__restrict__ regs,
+                         const float *__restrict__ scores, const int32_t *__restrict__ row_off,
+                         const float *__restrict__ image_sizes, int K, float score_thresh, float min_size,
+                         int cap, float4 *__restrict__ boxes_out, float *__restrict__ scores_out,
+                         int32_t *__restrict__ labels_out, int32_t *__restrict__ count_out)
+{
+    __shared__ int wave_sums[16];
+    __shared__ int s_prior[16];
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x;
+    const long long row0 = row_off[b];
+    const int M = (row_off[b + 1] - row_off[b]) * K;
+    if (tile * 1024 >= M && tile != 0) return; // (tile 0 still reports a zero count)
+    const float image_h = image_sizes[2 * b], image_w = image_sizes[2 * b + 1];
+    int prior = 0;
+    for (int u = threadIdx.x; u < tile; u += 1024) prior += labels_out[(long long)b * cap + M - 1 - u];
+    for (int o = 32; o > 0; o >>= 1) prior += __shfl_down(prior, o);
+    if ((threadIdx.x & 63) == 0) s_prior[threadIdx.x >> 6] = prior;
+    const int m = tile * 1024 + threadIdx.x;
+    float4 p = make_float4(0, 0, 0, 0);
+    float sc = 0.0f;
+    const bool keep = m < M && detect_keep(props, regs, scores, row0, m, K, image_h, image_w, score_thresh,
+                                           min_size, &p, &sc);
+    int tot;
+    int pos = frcnn_block_excl_count(keep, wave_sums, &tot); // (its barriers also publish s_prior)
+    int base = 0;
+    for (int w = 0; w < 16; ++w) base += s_prior[w];
+    pos += base;
+    if (keep) { // pos < r (K - 1) <= M - r: never one of the count slots
+        boxes_out[(long long)b * cap + pos] = p;
+        scores_out[(long long)b * cap + pos] = sc;
+        labels_out[(long long)b * cap + pos] = m % K;
+    }
+    if (threadIdx.x == 0 && (tile + 1) * 1024 >= M) count_out[b] = base + tot; // the image's last tile
+}
+
 extern "C" int frcnn_roi_detect_filter_f32(const float *props, const float *regs, const float *scores,
                                            const int32_t *row_off, const float *image_sizes, int B, int K,
                                            int max_rows, float score_thresh, float min_size, float *boxes_out,
@@ -546,7 +608,18 @@ extern "C" int frcnn_roi_detect_filter_f32(const float *props, const float *regs
         return FRCNN_OK;
     }
     FRCNN_REQUIRE(props && regs && scores && boxes_out && scores_out && labels_out, "roi_detect_filter: null pointer");
-    hipLaunchKernelGGL(roi_detect_filter_kernel, dim3((cap + 1023) / 1024, B), dim3(1024), 0, (hipStream_t)stream,
+    const dim3 grid((cap + 1023) / 1024, B);
+    if (K > 1024 || grid.x == 1) { // (a single tile has nothing before it)
+        hipLaunchKernelGGL(roi_detect_filter_rederive_kernel, grid, dim3(1024), 0, (hipStream_t)stream,
+                           (const float4 *)props, (const float4 *)regs, scores, row_off, image_sizes, K, score_thresh,
+                           min_size, cap, (float4 *)boxes_out, scores_out, labels_out, count_out);
+        FRCNN_CHECK_LAUNCH("roi_detect_filter");
+        return FRCNN_OK;
+    }
+    hipLaunchKernelGGL(roi_detect_count_kernel, grid, dim3(1024), 0, (hipStream_t)stream, (const float4 *)props,
+                       (const float4 *)regs, scores, row_off, image_sizes, K, score_thresh, min_size, cap, labels_out);
+    FRCNN_CHECK_LAUNCH("roi_detect_count");
+    hipLaunchKernelGGL(roi_detect_filter_kernel, grid, dim3(1024), 0, (hipStream_t)stream,
                        (const float4 *)props, (const float4 *)regs, scores, row_off, image_sizes, K, score_thresh,
                        min_size, cap, (float4 *)boxes_out, scores_out, labels_out, count_out);
     FRCNN_CHECK_LAUNCH("roi_detect_filter");

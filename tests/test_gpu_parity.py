@@ -972,6 +972,41 @@ def test_roi_head_eval_postprocess_vs_oracle(dev, oracle):
     assert total_det > 20
 
 
+@pytest.mark.parametrize("K,nprops,thresh", [(2, [3000, 1, 0, 2500], -1.0), (21, [400, 0, 37, 1], -1.0),
+                                             (21, [2000, 1500], 0.3), (1024, [5, 2], -1.0), (1025, [4, 3], -1.0),
+                                             (1, [2100, 5], -1.0)])
+def test_roi_detect_filter_counts_and_order(dev, oracle, K, nprops, thresh):
+    """The batched filter of roi_head.py:178-209, direct: every class-c>0 candidate kept (threshold below every
+    score), so each image fills all the rows it can -- right up to the slots in which the first launch leaves
+    its per-tile counts -- and a mid threshold; K = 1025 takes the one-launch kernel, K = 1 keeps nothing."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(K * 7 + len(nprops))
+    N = sum(nprops)
+    props = realistic_boxes(rng, N, 320, 256) if N else np.zeros((0, 4), np.float32)
+    regs = (rng.standard_normal((N, K * 4)) * 0.2).astype(np.float32)
+    scores = rng.random((N, K)).astype(np.float32)
+    sizes = [(256 - 3 * i, 320 - 5 * i) for i in range(len(nprops))]
+    row_off = np.concatenate([[0], np.cumsum(nprops)]).astype(np.int32)
+    bx, sc, lb, cnt = ops.roi_detect_filter(T(props, dev), T(regs, dev), T(scores, dev), T(row_off, dev, torch.int32),
+                                            T(np.asarray(sizes, np.float32), dev), max(nprops), thresh, 1e-3)
+    cnt = cnt.cpu().numpy()
+    for i, n in enumerate(nprops):
+        lo = row_off[i]
+        if n == 0:
+            assert cnt[i] == 0
+            continue
+        box = oracle.box_clip(oracle.box_regression(props[lo:lo + n], regs[lo:lo + n]).reshape(-1, 4), sizes[i])
+        s1 = scores[lo:lo + n].reshape(-1)
+        lab = np.tile(np.arange(K), n)
+        m = (s1 > np.float32(thresh)) & (lab > 0) & (box[:, 2] - box[:, 0] > np.float32(1e-3)) & \
+            (box[:, 3] - box[:, 1] > np.float32(1e-3))
+        assert cnt[i] == m.sum(), (i, cnt[i], m.sum())
+        c = int(cnt[i])
+        assert np.array_equal(lb[i, :c].cpu().numpy(), lab[m])
+        assert np.array_equal(sc[i, :c].cpu().numpy(), s1[m])
+        np.testing.assert_allclose(bx[i, :c].cpu().numpy(), box[m], rtol=RTOL, atol=1e-4)
+
+
 def test_sampled_losses_golden(dev, oracle):
     """fused gather + loss kernels against what torch / the reference's smooth_l1_loss
     produced (losses.npz), gradients through autograd included, and against the CPU restatement."""
