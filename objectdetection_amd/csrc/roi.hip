@@ -439,6 +439,18 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
         s_off = off;
         if (total_out && chunk == 0 && grp == 0) *total_out = tot;
     }
+    const float4 *pb = props + (long long)b * P;
+    if (n_levels > 1) {
+        // a pyramid level none of this split's RoIs maps to (the coarsest ones, mostly) is not staged at all
+        __syncthreads();
+        const int per_ = (s_cnt + splits - 1) / splits;
+        int mine = 0;
+        for (int i = split * per_ + (int)threadIdx.x; i < min(s_cnt, (split + 1) * per_); i += RAP_THREADS) {
+            const int lv = map_level(pb[i], k_min, k_max);
+            mine |= (lv == level) || ((lv < 0 || lv >= n_levels) && level == 0);
+        }
+        if (!__syncthreads_or(mine)) return;
+    }
     // stage the chunk's planes: 4 coalesced plane reads -> one 16-byte LDS write per pixel/group.
     // Four pixels per thread are fetched before any is written, so a workgroup pays about three
     // memory round trips for its 150 KB instead of nine.
@@ -477,7 +489,6 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
     const int j0 = split * per;
     const int j1 = min(cnt, j0 + per);
     const int row_stride = G * WS;
-    const float4 *pb = props + (long long)b * P;
     float *ob = out + ((long long)s_off * C + c0) * 49;
     // RoIs are taken RAP_SEG at a time: their geometry goes to LDS first, so that the item loop
     // below issues NO global loads.  The memory counter retires loads and stores in order; a box
