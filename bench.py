@@ -292,7 +292,7 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
                roofline=dict(bound="hbm", kernel="roi_align_plane_kernel", achieved=roi_bytes / (ra_ms * 1e-3) / 1e9,
                              peak=HBM_PEAK_GBPS, unit="GB/s", frac=roi_bytes / (ra_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              traffic=traffic, traffic_source="pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE, "
-                             "separate passes; profiles/r01_step6_roi_align_pmc.csv)" if traffic else None,
+                             "separate passes; profiles/r01_step12_roi_align_pmc.csv)" if traffic else None,
                              algorithmic_bytes_per_launch=roi_bytes, launch_ms=ra_ms,
                              dominant_stage=max(stage_ms, key=stage_ms.get)))
     return res, props, n_keep
