@@ -427,10 +427,16 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     if (dense && pm_tiles) {
         for (int i = t; i < NMS_RT * 64; i += 1024) s_tiles[i] = w.tiles[i];
     } else {
-        for (int id = wave; id < NMS_RT; id += 16) {
-            int rb, cb;
-            nms_tile_rc(id, &rb, &cb);
-            if (cb < nC) s_tiles[id * 64 + lane] = nms_tile_from_lds(s_box, count, rb, cb, lane, thr);
+        // the nC (nC + 1) / 2 tiles of the list, dealt to the waves in turn: every SIMD gets its share
+        const int nT = nC * (nC + 1) / 2;
+        for (int q = wave; q < nT; q += 16) {
+            int rb = 0, left = q;
+            while (left >= nC - rb) {
+                left -= nC - rb;
+                ++rb;
+            }
+            const int cb = rb + left;
+            s_tiles[nms_tile_id(rb, cb) * 64 + lane] = nms_tile_from_lds(s_box, count, rb, cb, lane, thr);
         }
     }
     __syncthreads();
