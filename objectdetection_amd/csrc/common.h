@@ -57,6 +57,20 @@ __device__ __forceinline__ float frcnn_iou(float ax1, float ay1, float ax2, floa
     return inter / ((aarea + barea) - inter);
 }
 
+__device__ __forceinline__ float frcnn_vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ float frcnn_vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Intersection and union terms of the IoU above, for callers that only need a threshold decision.
 __device__ __forceinline__ void frcnn_inter_union(float ax1, float ay1, float ax2, float ay2,
                                                   float aarea, float bx1, float by1, float bx2,
@@ -65,10 +79,12 @@ __device__ __forceinline__ void frcnn_inter_union(float ax1, float ay1, float ax
     // v_max_f32 / v_min_f32 (one instruction each instead of compare + select).  They drop a NaN operand
     // where torch.max / torch.min would propagate it, which cannot change a decision: a box with a NaN
     // coordinate has a NaN area, so `uni` is NaN and frcnn_iou_gt answers "not suppressed" either way.
-    float ltx = __builtin_fmaxf(ax1, bx1);
-    float lty = __builtin_fmaxf(ay1, by1);
-    float rbx = __builtin_fminf(ax2, bx2);
-    float rby = __builtin_fminf(ay2, by2);
+    // The instruction itself rather than fmaxf / fminf: for an operand that was loaded, not computed, the
+    // compiler puts a canonicalising v_max_f32 x, x in front of each (four more VALU operations per pair).
+    float ltx = frcnn_vmax(ax1, bx1);
+    float lty = frcnn_vmax(ay1, by1);
+    float rbx = frcnn_vmin(ax2, bx2);
+    float rby = frcnn_vmin(ay2, by2);
     float jw = __builtin_fmaxf(rbx - ltx, 0.0f);
     float jh = __builtin_fmaxf(rby - lty, 0.0f);
     *inter = jw * jh;
@@ -94,13 +110,37 @@ __device__ __forceinline__ bool frcnn_iou_gt(float inter, float uni, const Frcnn
     const float d = inter - p;
     // p = +inf or NaN (huge or non-finite union) fails the last comparison by itself: inf > inf and
     // NaN > x are false
-    const bool sure = th.fast && (p > 1e-30f) && (fabsf(d) > p * 9.5367431640625e-07f);
+    const bool sure = (p > 1e-30f) && (fabsf(d) > p * 9.5367431640625e-07f);
     bool r = d > 0.0f;
-    if (__builtin_expect(__any(!sure), 0)) { // wave-uniform: taken about once per 2^14 wave tests
+    // wave-uniform, taken about once per 2^14 wave tests.  (`th.fast` stays out of the per-lane mask: OR-ed
+    // into it, the compiler rebuilds the ballot with two more VALU operations per pair.)
+    if (__builtin_expect(!th.fast || __ballot(sure) != __builtin_amdgcn_read_exec(), 0)) {
         const bool slow = (inter / uni) > th.t;
-        r = sure ? r : slow;
+        r = (th.fast && sure) ? r : slow;
     }
     return r;
+}
+
+// The same test for loops over many pairs, in two halves: the multiply decision, and -- AND-ed into `sure` over
+// a GROUP of pairs -- whether it is safe.  A group with an unsafe pair (frcnn_group_unsure, wave-uniform, about
+// one pair in 2^20) is redone with the division for every lane, which is the definition of the test; the
+// per-pair cost is then the decision alone, and the mask bookkeeping (two VALU operations) is paid per group.
+__device__ __forceinline__ bool frcnn_iou_gt_fast(float inter, float uni, const FrcnnThr &th, bool &sure)
+{
+    const float p = th.t2 * uni;
+    const float d = inter - p;
+    sure = sure && (p > 1e-30f) && (fabsf(d) > p * 9.5367431640625e-07f);
+    return d > 0.0f;
+}
+
+__device__ __forceinline__ bool frcnn_iou_gt_exact(float inter, float uni, const FrcnnThr &th)
+{
+    return (inter / uni) > th.t;
+}
+
+__device__ __forceinline__ bool frcnn_group_unsure(bool sure, const FrcnnThr &th)
+{
+    return !th.fast || __ballot(sure) != __builtin_amdgcn_read_exec();
 }
 
 // Kernel attributes are per device: remember, per device, the largest dynamic-LDS size already granted to a

@@ -240,12 +240,60 @@ __device__ __forceinline__ int nms_tile_id(int rb, int cb)
     return rb * NMS_RC - rb * (rb - 1) / 2 + (cb - rb);
 }
 
+// One 64x64 tile of COLUMN words: lane = column candidate, the 64 row candidates (boxes and areas) are
+// broadcast from LDS.  Bit i of a lane's word = "row i suppresses me".  32 rows at a time, highest first, so
+// that a word grows as word * 2 + bit (one add-with-carry); the threshold test is the grouped form of
+// common.h: a half tile with an unsafe pair is redone with the division.
+template <bool EXACT>
+__device__ __forceinline__ unsigned nms_tile_rows32(const float4 *rows, const float *rarea, const float4 &c,
+                                                    float carea, const FrcnnThr &thr, bool &sure)
+{
+    unsigned w = 0;
+#pragma unroll 8
+    for (int i = 31; i >= 0; --i) {
+        const float4 r = rows[i];
+        float inter, uni;
+        frcnn_inter_union(r.x, r.y, r.z, r.w, rarea[i], c.x, c.y, c.z, c.w, carea, &inter, &uni);
+        const bool s = EXACT ? frcnn_iou_gt_exact(inter, uni, thr) : frcnn_iou_gt_fast(inter, uni, thr, sure);
+        w = w + w + (s ? 1u : 0u);
+    }
+    return w;
+}
+
+__device__ __forceinline__ unsigned long long nms_tile_words(const float4 *rows, const float *rarea,
+                                                             const float4 &c, float carea, const FrcnnThr &thr)
+{
+    unsigned h[2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        bool sure = true;
+        unsigned w = nms_tile_rows32<false>(rows + 32 * half, rarea + 32 * half, c, carea, thr, sure);
+        if (__builtin_expect(frcnn_group_unsure(sure, thr), 0))
+            w = nms_tile_rows32<true>(rows + 32 * half, rarea + 32 * half, c, carea, thr, sure);
+        h[half] = w;
+    }
+    return ((unsigned long long)h[1] << 32) | h[0];
+}
+
+// A tile of the candidate list held in LDS (the scan kernel's own tiles).  Rows or columns beyond `count`
+// hold stale boxes: they are marked removed, so their bits are never looked at.
+__device__ __forceinline__ unsigned long long nms_tile_from_lds(const float4 *s_box, const float *s_area, int rb,
+                                                                int cb, int lane, const FrcnnThr &thr)
+{
+    const float4 c = s_box[cb * 64 + lane];
+    unsigned long long word = nms_tile_words(s_box + rb * 64, s_area + rb * 64, c, s_area[cb * 64 + lane], thr);
+    if (rb == cb) word &= (1ull << lane) - 1ull; // only earlier candidates of the same block
+    return word;
+}
+
 // Kernel PM of a round.  grid = (16 candidate blocks, RSPLIT pull slices + tile slices, B).
 __global__ void __launch_bounds__(256)
 nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
                     int max_n, FrcnnThr thr, int max_keep, int cap, int round, int rsplit, char *ws,
                     size_t ws_stride)
 {
+    __shared__ float4 s_rows[4][64]; // a tile wave's row block
+    __shared__ float s_rarea[4][64];
     const int b = blockIdx.z;
     const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
     const int base = round * NMS_RS;
@@ -267,23 +315,49 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
         bool sup = false;
         const int step = rsplit * 4;
         int r = blockIdx.y * 4 + wave;
-        // the next kept box is fetched while the current one is tested
-        float4 k_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        float a_next = 0.0f;
-        if (r < nk) {
-            k_next = w.kbox[r];
-            a_next = w.karea[r];
-        }
-        for (; r < nk; r += step) {
-            const float4 k = k_next;
-            const float ka = a_next;
-            if (r + step < nk) {
-                k_next = w.kbox[r + step];
-                a_next = w.karea[r + step];
+        // Four kept boxes (r, r + step, ...) per group: the next group is fetched while this one is tested,
+        // into the other of two register sets, and the threshold test is the grouped form of common.h.
+        float4 ka[4], kb[4];
+        float aa[4], ab[4];
+        auto fetch = [&](int r0, float4 (&k)[4], float (&a)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rj = r0 + j * step;
+                k[j] = zero4;
+                a[j] = 0.0f;
+                if (rj < nk) {
+                    k[j] = w.kbox[rj];
+                    a[j] = w.karea[rj];
+                }
             }
-            float inter, uni;
-            frcnn_inter_union(k.x, k.y, k.z, k.w, ka, cb.x, cb.y, cb.z, cb.w, carea, &inter, &uni);
-            sup = sup | frcnn_iou_gt(inter, uni, thr);
+        };
+        auto test = [&](int r0, const float4 (&k)[4], const float (&a)[4]) {
+            float inter[4], uni[4];
+            bool sure = true, s = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                frcnn_inter_union(k[j].x, k[j].y, k[j].z, k[j].w, a[j], cb.x, cb.y, cb.z, cb.w, carea, &inter[j],
+                                  &uni[j]);
+                const bool sj = frcnn_iou_gt_fast(inter[j], uni[j], thr, sure);
+                s = s | (sj && r0 + j * step < nk);
+            }
+            if (__builtin_expect(frcnn_group_unsure(sure, thr), 0)) {
+                s = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s = s | (frcnn_iou_gt_exact(inter[j], uni[j], thr) && r0 + j * step < nk);
+            }
+            sup = sup | s;
+        };
+        const int gstep = 4 * step;
+        if (r < nk) fetch(r, ka, aa);
+        while (r < nk) {
+            if (r + gstep < nk) fetch(r + gstep, kb, ab);
+            test(r, ka, aa);
+            r += gstep;
+            if (r >= nk) break;
+            if (r + gstep < nk) fetch(r + gstep, ka, aa);
+            test(r, kb, ab);
+            r += gstep;
         }
         const unsigned long long m = __ballot(sup);
         if (lane == 0 && m != 0) atomicOr(&w.sup[c], m);
@@ -306,51 +380,16 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
         // COLUMN words: bit i of lane c's word = "row candidate i suppresses column candidate c".
         // With the suppressors of a candidate in its own lane, the scan kernel needs no cross-lane
         // reduction: `(word & kept_mask) != 0` is lane-local and a ballot collects the block.
-        unsigned lo = 0, hi = 0;
-#pragma unroll 8
-        for (int i = 0; i < 64; ++i) {
-            const float x1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.x), i));
-            const float y1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.y), i));
-            const float x2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.z), i));
-            const float y2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rbx.w), i));
-            const float ra = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rarea), i));
-            float inter, uni;
-            frcnn_inter_union(x1, y1, x2, y2, ra, cbx.x, cbx.y, cbx.z, cbx.w, carea, &inter, &uni);
-            const bool sup = frcnn_iou_gt(inter, uni, thr) && ci < n && (!diag || lane > i);
-            if (i < 32)
-                lo |= sup ? (1u << i) : 0u;
-            else
-                hi |= sup ? (1u << (i - 32)) : 0u;
-        }
-        const unsigned long long word = ((unsigned long long)hi << 32) | lo;
+        // The row block goes through a wave-private piece of LDS: one broadcast read per row instead of five
+        // cross-lane register reads.  (Candidates beyond n are marked removed by the scan: their bits are unused.)
+        s_rows[wave][lane] = rbx;
+        s_rarea[wave][lane] = rarea;
+        __builtin_amdgcn_wave_barrier();
+        unsigned long long word = nms_tile_words(s_rows[wave], s_rarea[wave], cbx, carea, thr);
+        if (diag) word &= (1ull << lane) - 1ull;
+        if (ci >= n) word = 0;
         w.tiles[(long long)id * 64 + lane] = word;
     }
-}
-
-// One 64x64 tile of COLUMN words over a candidate list held in LDS: lane = column candidate
-// cb*64+lane, rows rb*64+i broadcast from LDS.  Bit i of a lane's word = "row i suppresses me".
-__device__ __forceinline__ unsigned long long nms_tile_from_lds(const float4 *s_box, int count, int rb,
-                                                                int cb, int lane, const FrcnnThr &thr)
-{
-    const int ci = cb * 64 + lane;
-    const float4 c = s_box[ci];
-    const float carea = frcnn_area(c.x, c.y, c.z, c.w);
-    const bool diag = rb == cb;
-    unsigned lo = 0, hi = 0;
-#pragma unroll 8
-    for (int i = 0; i < 64; ++i) {
-        const float4 r = s_box[rb * 64 + i];
-        float inter, uni;
-        frcnn_inter_union(r.x, r.y, r.z, r.w, frcnn_area(r.x, r.y, r.z, r.w), c.x, c.y, c.z, c.w, carea,
-                          &inter, &uni);
-        const bool sup = frcnn_iou_gt(inter, uni, thr) && ci < count && rb * 64 + i < count &&
-                         (!diag || lane > i);
-        if (i < 32)
-            lo |= sup ? (1u << i) : 0u;
-        else
-            hi |= sup ? (1u << (i - 32)) : 0u;
-    }
-    return ((unsigned long long)hi << 32) | lo;
 }
 
 // Kernel L of a round: one workgroup per image resolves the round's candidates in order.
@@ -365,6 +404,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
 {
     __shared__ unsigned long long s_tiles[NMS_RT * 64];
     __shared__ float4 s_box[NMS_RS];   // the list's boxes
+    __shared__ float s_area[NMS_RS];   // and their areas
     __shared__ int s_pos[NMS_RS];      // the list's positions inside the round
     __shared__ unsigned long long s_removed[NMS_RC];
     __shared__ unsigned long long s_K[NMS_RC];
@@ -404,6 +444,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     if (dense) {
         count = cnt;
         s_box[t] = mybox;
+        s_area[t] = frcnn_area(mybox.x, mybox.y, mybox.z, mybox.w);
         s_pos[t] = t;
         __syncthreads();
     } else {
@@ -415,6 +456,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
         __syncthreads(); // everyone has read the pull words
         if (!((rm >> lane) & 1ull)) {
             s_box[rank] = mybox;
+            s_area[rank] = frcnn_area(mybox.x, mybox.y, mybox.z, mybox.w);
             s_pos[rank] = t;
         }
         if (t < NMS_RC) { // the compacted list starts with nothing removed but its tail
@@ -436,7 +478,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
                 ++rb;
             }
             const int cb = rb + left;
-            s_tiles[nms_tile_id(rb, cb) * 64 + lane] = nms_tile_from_lds(s_box, count, rb, cb, lane, thr);
+            s_tiles[nms_tile_id(rb, cb) * 64 + lane] = nms_tile_from_lds(s_box, s_area, rb, cb, lane, thr);
         }
     }
     __syncthreads();
@@ -497,7 +539,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
             for (int cc = 0; cc < wave; ++cc) pos += __popcll(s_K[cc]);
             const float4 bxv = s_box[t];
             w.kbox[pos] = bxv;
-            w.karea[pos] = frcnn_area(bxv.x, bxv.y, bxv.z, bxv.w);
+            w.karea[pos] = s_area[t];
             keep_out[(long long)b * max_keep + pos] = base + s_pos[t];
         }
     }
