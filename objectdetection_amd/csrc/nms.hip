@@ -188,6 +188,7 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
 #define NMS_RC (NMS_RS / 64)              // 64-candidate blocks per round (16)
 #define NMS_RT (NMS_RC * (NMS_RC + 1) / 2) // upper-triangular tiles per round (136)
 #define NMS_DENSE 512                     // survivors per round from which chip-wide tiles pay off
+#define NMS_TILE_WORDS ((NMS_RT * 64 + 1023) / 1024) // tile words per thread of the scan kernel (9)
 #define NMS_TILE_GROUPS ((NMS_RT + NMS_RC * 4 - 1) / (NMS_RC * 4)) // grid.y slices of tile waves (3)
 
 // Per-image workspace of the round path (all offsets 16-byte aligned).
@@ -423,6 +424,15 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     const int wave = t >> 6;
     const int cnt = min(NMS_RS, n - base);
     const bool pm_tiles = round == 0 || *w.dense != 0; // what kernel PM decided for this image
+    // Everything this workgroup reads from memory is requested here, in one round trip: its candidate, and
+    // kernel PM's tiles (from all over the chip, so from beyond this XCD's L2) if there are any -- whether
+    // they are used is only known once the pull words are in.
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 mybox = t < cnt ? boxes[(long long)b * max_n + base + t] : zero4;
+    unsigned long long tv[NMS_TILE_WORDS];
+#pragma unroll
+    for (int u = 0; u < NMS_TILE_WORDS; ++u)
+        tv[u] = (pm_tiles && t + u * 1024 < NMS_RT * 64) ? w.tiles[t + u * 1024] : 0ull;
     // survivors of the pull
     unsigned long long pulled = 0;
     if (t < NMS_RC) {
@@ -438,8 +448,6 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     int alive = 0;
     for (int c = 0; c < NMS_RC; ++c) alive += 64 - __popcll(s_removed[c]);
     const bool dense = alive >= NMS_DENSE;
-    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float4 mybox = t < cnt ? boxes[(long long)b * max_n + base + t] : zero4;
     int count; // length of the list
     if (dense) {
         count = cnt;
@@ -467,7 +475,9 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     }
     const int nC = (count + 63) >> 6;
     if (dense && pm_tiles) {
-        for (int i = t; i < NMS_RT * 64; i += 1024) s_tiles[i] = w.tiles[i];
+#pragma unroll
+        for (int u = 0; u < NMS_TILE_WORDS; ++u)
+            if (t + u * 1024 < NMS_RT * 64) s_tiles[t + u * 1024] = tv[u];
     } else {
         // the nC (nC + 1) / 2 tiles of the list, dealt to the waves in turn: every SIMD gets its share
         const int nT = nC * (nC + 1) / 2;
