@@ -84,14 +84,13 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
         s_rem[0] = 0;
         s_rem[1] = 0;
     }
-    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     int nkeep_final = 0;
     for (int c0 = 0; c0 < Wn; c0 += NMS_LAZY_WAVES) {
         // refill: one coalesced 16-KB read serves the next 16 candidate blocks; no global memory
         // operation is issued inside the per-block loop below, so its barriers are cheap
         {
             int idx = c0 * 64 + threadIdx.x;
-            s_cand[threadIdx.x] = idx < n ? bx[idx] : zero4;
+            s_cand[threadIdx.x] = bx[min(idx, n - 1)]; // (beyond n: marked removed below)
         }
         __syncthreads();
         const int cend = min(Wn, c0 + NMS_LAZY_WAVES);
@@ -314,51 +313,46 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
         const float4 cb = idx < n ? bx[idx] : zero4;
         const float carea = frcnn_area(cb.x, cb.y, cb.z, cb.w);
         bool sup = false;
-        const int step = rsplit * 4;
-        int r = blockIdx.y * 4 + wave;
-        // Four kept boxes (r, r + step, ...) per group: the next group is fetched while this one is tested,
-        // into the other of two register sets, and the threshold test is the grouped form of common.h.
-        float4 ka[4], kb[4];
-        float aa[4], ab[4];
-        auto fetch = [&](int r0, float4 (&k)[4], float (&a)[4]) {
+        // The workgroup's slice of the kept list goes through LDS 256 rows at a time, one row per thread, the
+        // next 256 requested before these are tested: two or three memory round trips per workgroup instead of
+        // one per group of pairs (four waves per SIMD do not hide those).  Wave w tests rows w, w + 4, ... of
+        // the 256, four per group, with the grouped threshold test of common.h.
+        float4 *s_k = &s_rows[0][0];
+        float *s_ka = &s_rarea[0][0];
+        const int per = ((nk + rsplit - 1) / rsplit + 3) & ~3;
+        const int r_begin = blockIdx.y * per, r_end = min(nk, r_begin + per);
+        if (r_begin >= r_end) return;
+        // (rows beyond the slice: the slice's last row again -- never tested, see `row < m` below)
+        float4 pk = w.kbox[min(r_begin + (int)threadIdx.x, r_end - 1)];
+        float pa = w.karea[min(r_begin + (int)threadIdx.x, r_end - 1)];
+        for (int r0 = r_begin; r0 < r_end; r0 += 256) {
+            __syncthreads(); // the previous 256 have been tested
+            s_k[threadIdx.x] = pk;
+            s_ka[threadIdx.x] = pa;
+            __syncthreads();
+            pk = w.kbox[min(r0 + 256 + (int)threadIdx.x, r_end - 1)];
+            pa = w.karea[min(r0 + 256 + (int)threadIdx.x, r_end - 1)];
+            const int m = min(256, r_end - r0); // rows of this piece
+            for (int g = 0; g * 4 + wave < m; g += 4) {
+                float inter[4], uni[4];
+                bool sure = true, s = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int rj = r0 + j * step;
-                k[j] = zero4;
-                a[j] = 0.0f;
-                if (rj < nk) {
-                    k[j] = w.kbox[rj];
-                    a[j] = w.karea[rj];
+                for (int j = 0; j < 4; ++j) {
+                    const int row = (g + j) * 4 + wave; // < 256 + 12: the arrays end at 256, so clamp
+                    const float4 k = s_k[min(row, 255)];
+                    frcnn_inter_union(k.x, k.y, k.z, k.w, s_ka[min(row, 255)], cb.x, cb.y, cb.z, cb.w, carea,
+                                      &inter[j], &uni[j]);
+                    const bool sj = frcnn_iou_gt_fast(inter[j], uni[j], thr, sure);
+                    s = s | (sj && row < m);
                 }
-            }
-        };
-        auto test = [&](int r0, const float4 (&k)[4], const float (&a)[4]) {
-            float inter[4], uni[4];
-            bool sure = true, s = false;
+                if (__builtin_expect(frcnn_group_unsure(sure, thr), 0)) {
+                    s = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                frcnn_inter_union(k[j].x, k[j].y, k[j].z, k[j].w, a[j], cb.x, cb.y, cb.z, cb.w, carea, &inter[j],
-                                  &uni[j]);
-                const bool sj = frcnn_iou_gt_fast(inter[j], uni[j], thr, sure);
-                s = s | (sj && r0 + j * step < nk);
+                    for (int j = 0; j < 4; ++j)
+                        s = s | (frcnn_iou_gt_exact(inter[j], uni[j], thr) && (g + j) * 4 + wave < m);
+                }
+                sup = sup | s;
             }
-            if (__builtin_expect(frcnn_group_unsure(sure, thr), 0)) {
-                s = false;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) s = s | (frcnn_iou_gt_exact(inter[j], uni[j], thr) && r0 + j * step < nk);
-            }
-            sup = sup | s;
-        };
-        const int gstep = 4 * step;
-        if (r < nk) fetch(r, ka, aa);
-        while (r < nk) {
-            if (r + gstep < nk) fetch(r + gstep, kb, ab);
-            test(r, ka, aa);
-            r += gstep;
-            if (r >= nk) break;
-            if (r + gstep < nk) fetch(r + gstep, ka, aa);
-            test(r, kb, ab);
-            r += gstep;
         }
         const unsigned long long m = __ballot(sup);
         if (lane == 0 && m != 0) atomicOr(&w.sup[c], m);
@@ -427,8 +421,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     // Everything this workgroup reads from memory is requested here, in one round trip: its candidate, and
     // kernel PM's tiles (from all over the chip, so from beyond this XCD's L2) if there are any -- whether
     // they are used is only known once the pull words are in.
-    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float4 mybox = t < cnt ? boxes[(long long)b * max_n + base + t] : zero4;
+    const float4 mybox = boxes[(long long)b * max_n + base + min(t, cnt - 1)]; // (beyond cnt: marked removed below)
     unsigned long long tv[NMS_TILE_WORDS];
 #pragma unroll
     for (int u = 0; u < NMS_TILE_WORDS; ++u)
