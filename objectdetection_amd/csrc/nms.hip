@@ -501,16 +501,20 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
             if (c < nC && nk < max_keep) {
                 const int tb = nms_tile_id(c, c);
                 const unsigned long long col = s_tiles[tb * 64 + lane];
+                // the block's words in the later blocks' tiles: requested together, ahead of the resolve loop
+                // (one LDS latency per block instead of one per later block; beyond nC they are never used)
+                unsigned long long cw[NMS_RC];
+#pragma unroll
+                for (int cb = c + 1; cb < NMS_RC; ++cb) cw[cb] = s_tiles[(tb + cb - c) * 64 + lane];
                 unsigned long long U = ~removed[c]; // undecided
                 unsigned long long K = 0;           // decided: kept
+                // (all 64 lanes are active, and a ballot of a bare comparison is its mask: the rest is scalar)
                 while (U != 0) {
-                    const bool inU = (U >> lane) & 1ull;
-                    const bool killed = (col & K) != 0;
-                    const bool blocked = (col & U) != 0;
-                    const unsigned long long rem_now = __ballot(inU && killed);
-                    const unsigned long long keep_now = __ballot(inU && !killed && !blocked);
+                    const unsigned long long killed = __ballot((col & K) != 0);
+                    const unsigned long long busy = __ballot((col & (K | U)) != 0); // killed, or waiting for an undecided one
+                    const unsigned long long keep_now = U & ~busy;
                     K |= keep_now;
-                    U &= ~(rem_now | keep_now);
+                    U &= ~(killed | keep_now);
                 }
                 // only the first (max_keep - nk) keeps count: drop the highest surplus bits
                 int surplus = __popcll(K) - (max_keep - nk);
@@ -522,12 +526,8 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
                 nk += __popcll(K);
                 if (K != 0 && nk < max_keep) {
 #pragma unroll
-                    for (int cb = c + 1; cb < NMS_RC; ++cb) {
-                        if (cb < nC) {
-                            const unsigned long long cw = s_tiles[(tb + cb - c) * 64 + lane];
-                            removed[cb] |= __ballot((cw & K) != 0);
-                        }
-                    }
+                    for (int cb = c + 1; cb < NMS_RC; ++cb)
+                        if (cb < nC) removed[cb] |= __ballot((cw[cb] & K) != 0);
                 }
             }
         }

@@ -11,6 +11,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
+if os.environ.get("FRCNN_EXP_LIB"):  # A/B builds of the library (experiments only)
+    import objectdetection_amd._lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["FRCNN_EXP_LIB"])
+
 
 def main():
     what = sys.argv[1]
