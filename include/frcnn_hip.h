@@ -135,7 +135,9 @@ int frcnn_decode_clip_filter_nchw_f32(const float *anchors, int64_t anchor_batch
  * n_per_image: (B) int32 device, or NULL for max_n everywhere.  Box j is suppressed by an earlier
  * kept box i when (double)iou_f32(i,j) > iou_threshold; NaN never suppresses.  Stops after
  * max_keep keeps (the reference's [:num_post_nms]).
- * keep_out: (B, max_keep) positions into the image's rows, in keep order; n_keep_out: (B). */
+ * keep_out: (B, max_keep) positions into the image's rows, in keep order; n_keep_out: (B).
+ * workspace: frcnn_nms_workspace_bytes(B, max_n) bytes of device memory (0 for max_n <= 2048); its
+ * contents on entry do not matter. */
 size_t frcnn_nms_workspace_bytes(int B, int max_n);
 int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
                          double iou_threshold, int max_keep, int32_t *keep_out,

@@ -299,7 +299,7 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
     const int base = round * NMS_RS;
     if (base >= n) return;
     const NmsWs w = nms_ws(ws, ws_stride, b, cap);
-    const int nk = *w.nkeep;
+    const int nk = round == 0 ? 0 : *w.nkeep; // (round 0 reads nothing of the workspace: it need not be cleared)
     if (nk >= max_keep) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -408,9 +408,14 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
     const int base = round * NMS_RS;
     const NmsWs w = nms_ws(ws, ws_stride, b, cap);
-    const int nk0 = *w.nkeep;
+    // Round 0 reads nothing of the workspace and leaves count, pull words and flag behind for the later rounds,
+    // so the caller's buffer needs no clearing.
+    const int nk0 = round == 0 ? 0 : *w.nkeep;
     if (base >= n || nk0 >= max_keep) {
-        if (threadIdx.x == 0) n_keep_out[b] = nk0;
+        if (threadIdx.x == 0) {
+            n_keep_out[b] = nk0;
+            if (round == 0) *w.nkeep = 0; // (an empty image: what the later rounds report)
+        }
         return;
     }
     const int t = threadIdx.x;
@@ -431,7 +436,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     if (t < NMS_RC) {
         const int rows = min(64, cnt - t * 64);
         const unsigned long long valid = rows >= 64 ? ~0ull : (rows <= 0 ? 0ull : ((1ull << rows) - 1ull));
-        pulled = w.sup[t] | ~valid;
+        pulled = (round == 0 ? 0ull : w.sup[t]) | ~valid;
         s_removed[t] = pulled;
         s_K[t] = 0;
         w.sup[t] = 0; // ready for the next round's atomicOr
@@ -614,10 +619,6 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
     }
     // the kept-list capacity of the workspace is max_n whatever max_keep is
     const size_t stride = nms_ws_stride(max_n);
-    {   // zero every image's pull words and keep counter (the tail of each image's slab)
-        hipError_t e = hipMemsetAsync(workspace, 0, (size_t)B * stride, st);
-        FRCNN_REQUIRE(e == hipSuccess, "nms: memset failed: %s", hipGetErrorString(e));
-    }
     const int rounds = (max_n + NMS_RS - 1) / NMS_RS;
     int rsplit = (1024 + NMS_RC * B - 1) / (NMS_RC * B); // pull slices: ~1024 workgroups in flight
     if (rsplit < 1) rsplit = 1;

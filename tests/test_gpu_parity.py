@@ -754,6 +754,33 @@ def test_nms_size_sweep(dev, oracle):
             assert np.array_equal(keep[b, :len(ref)].cpu().numpy(), ref), (n, max_keep, thr, b)
 
 
+def test_nms_workspace_needs_no_clearing(dev, oracle):
+    """The round path (n > 2048) through the C ABI with a workspace full of 0xFF bytes: round 0 reads nothing of
+    it, so the caller need not clear it.  Images with 0, 1, 700 (one round), 2,500 and 3,000 candidates."""
+    from objectdetection_amd import _lib
+    rng = np.random.default_rng(31)
+    ns = [0, 1, 700, 2500, 3000]
+    B, n, P = len(ns), 3000, 600
+    boxes = np.stack([realistic_boxes(rng, n, 320, 256) for _ in ns])
+    bx = T(boxes, dev)
+    cnt = T(np.asarray(ns, np.int32), dev, torch.int32)
+    lib = _lib.load()
+    nbytes = lib.frcnn_nms_workspace_bytes(B, n)
+    assert nbytes > 0
+    ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=dev)
+    keep = torch.full((B, P), -7, dtype=torch.int32, device=dev)
+    n_keep = torch.full((B,), -7, dtype=torch.int32, device=dev)
+    rc = lib.frcnn_nms_sorted_f32(bx.data_ptr(), cnt.data_ptr(), B, n, 0.7, P, keep.data_ptr(), n_keep.data_ptr(),
+                                  ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.frcnn_last_error_string()
+    torch.cuda.synchronize()
+    nk = n_keep.cpu().numpy()
+    for i, m in enumerate(ns):
+        ref = oracle.nms(boxes[i, :m], np.arange(m, 0, -1, dtype=np.float32), 0.7)[:P] if m else np.zeros((0,), np.int64)
+        assert nk[i] == len(ref), (i, nk[i], len(ref))
+        assert np.array_equal(keep[i, :nk[i]].cpu().numpy(), ref)
+
+
 def test_roi_pool_max_vs_oracle(dev, oracle):
     from objectdetection_amd import ops
     rng = np.random.default_rng(11)
