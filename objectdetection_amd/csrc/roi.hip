@@ -907,7 +907,10 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
     FRCNN_REQUIRE(sampling_ratio >= 1, "roi_align_batched: sampling_ratio must be >= 1 (got %d)", sampling_ratio);
     FRCNN_REQUIRE((long long)pooled_h * pooled_w * sampling_ratio * sampling_ratio <= RA_MAX_SAMPLES,
                   "roi_align_batched: pooled_h*pooled_w*sampling_ratio^2 exceeds %d", RA_MAX_SAMPLES);
-    const int WS = (W + 15) & ~15;                       // LDS row stride of the plane kernel
+    // LDS row stride of the plane kernel: the compile-time 64 for every map at most 64 pixels wide whose 16
+    // channels still fit (coarse pyramid levels included), else W rounded up to 16
+    int WS = (W + 15) & ~15;
+    if (W <= 64 && (long long)H * 64 * 4 * 16 <= RAP_LDS_BUDGET) WS = 64;
     const long long plane_bytes = (long long)H * WS * 4; // LDS bytes per channel
     if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && plane_bytes * 4 <= RAP_LDS_BUDGET &&
         (long long)P * 49 < (1ll << 30) && (long long)H * WS * 4 < (1 << 23)) {
@@ -924,10 +927,13 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         size_t lds = (size_t)plane_bytes * (size_t)CC;
         // fast instantiation: full 16-channel chunks on a map at most 64 pixels wide
         const bool full = (CC == 16) && (C % 16 == 0) && WS == 64;
+        // wider maps whose chunks are 8 whole channels (FPN P4 at 800 x 1344): channel groups known, stride not
+        const bool half = !full && (CC == 8) && (C % 8 == 0);
         {
-            static size_t granted4[FRCNN_MAX_DEVICES], granted0[FRCNN_MAX_DEVICES];
-            hipError_t e = full ? frcnn_reserve_dynamic_lds((const void *)roi_align_plane_kernel<4, 64>, lds, granted4)
-                                : frcnn_reserve_dynamic_lds((const void *)roi_align_plane_kernel<0, 0>, lds, granted0);
+            static size_t granted4[FRCNN_MAX_DEVICES], granted2[FRCNN_MAX_DEVICES], granted0[FRCNN_MAX_DEVICES];
+            hipError_t e = full   ? frcnn_reserve_dynamic_lds((const void *)roi_align_plane_kernel<4, 64>, lds, granted4)
+                           : half ? frcnn_reserve_dynamic_lds((const void *)roi_align_plane_kernel<2, 0>, lds, granted2)
+                                  : frcnn_reserve_dynamic_lds((const void *)roi_align_plane_kernel<0, 0>, lds, granted0);
             FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
                           hipGetErrorString(e));
         }
@@ -936,6 +942,10 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         const dim3 grid((unsigned)(groups8 * chunks));
         if (full)
             hipLaunchKernelGGL((roi_align_plane_kernel<4, 64>), grid, dim3(RAP_THREADS), lds,
+                               (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
+                               spatial_scale, level, n_levels, k_min, k_max, chunks, splits, B, out, total_out);
+        else if (half)
+            hipLaunchKernelGGL((roi_align_plane_kernel<2, 0>), grid, dim3(RAP_THREADS), lds,
                                (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, CC,
                                spatial_scale, level, n_levels, k_min, k_max, chunks, splits, B, out, total_out);
         else
