@@ -186,6 +186,9 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
 #define NMS_RS 1024                       // candidates per round
 #define NMS_RC (NMS_RS / 64)              // 64-candidate blocks per round (16)
 #define NMS_RT (NMS_RC * (NMS_RC + 1) / 2) // upper-triangular tiles per round (136)
+#ifndef NMS_PULL_WGS
+#define NMS_PULL_WGS 1024
+#endif
 #define NMS_DENSE 512                     // survivors per round from which chip-wide tiles pay off
 #define NMS_TILE_WORDS ((NMS_RT * 64 + 1023) / 1024) // tile words per thread of the scan kernel (9)
 #define NMS_TILE_GROUPS ((NMS_RT + NMS_RC * 4 - 1) / (NMS_RC * 4)) // grid.y slices of tile waves (3)
@@ -620,7 +623,7 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
     // the kept-list capacity of the workspace is max_n whatever max_keep is
     const size_t stride = nms_ws_stride(max_n);
     const int rounds = (max_n + NMS_RS - 1) / NMS_RS;
-    int rsplit = (1024 + NMS_RC * B - 1) / (NMS_RC * B); // pull slices: ~1024 workgroups in flight
+    int rsplit = (NMS_PULL_WGS + NMS_RC * B - 1) / (NMS_RC * B); // pull slices: ~NMS_PULL_WGS workgroups in flight
     if (rsplit < 1) rsplit = 1;
     if (rsplit > 16) rsplit = 16;
     for (int r = 0; r < rounds; ++r) {
