@@ -298,6 +298,75 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
     return res, props, n_keep
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started by hand (no WORLD_SIZE in the environment): start N fresh child
+    processes, one rank per GPU, BEFORE this process makes any GPU call (it never does: it only waits),
+    relay rank 0's JSON line and exit non-zero if any rank fails.  Under torch.distributed.run the ranks
+    already exist and this is not used."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()  # ends when rank 0 closes its stdout (exit included)
+    codes = []
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=300))
+        except subprocess.TimeoutExpired:  # rank 0 is gone and this one still runs: it is stuck in a collective
+            p.kill()
+            codes.append(p.wait())
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        sys.exit("bench.py: ranks exited with %r" % (codes,))
+
+
+def dry_run(args, world, rank):
+    """CPU rehearsal of the multi-rank protocol (no kernel runs, nothing is measured): process group over
+    gloo, the barrier + max-over-ranks timing bracket around K empty steps, the final proposal gather.
+    Exists so that the launcher and the rank plumbing can be tested where there is no GPU."""
+    import torch.distributed as dist
+    from objectdetection_amd.sharding import gather_proposals
+    if world > 1:
+        dist.init_process_group("gloo")
+    B = args.batch
+    props = torch.full((B, 8, 4), float(rank))
+    n_keep = torch.full((B,), rank + 1, dtype=torch.int32)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    gather_ms = None
+    n_ranks = 1
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g0 = time.perf_counter()
+        all_props, all_counts = gather_proposals(props, n_keep, dist)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        n_ranks = dist.get_world_size()
+        assert all_props.shape[0] == n_ranks * B
+        assert all_counts.tolist() == [r + 1 for r in range(n_ranks) for _ in range(B)]
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec RPN proposal+RoIPool", "value": None, "unit": "images/s",
+                          "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "dry_run": True,
+                          "gather_ms": gather_ms, "max_rank_elapsed_s": float(t.item()),
+                          "data": "none (CPU rehearsal of the rank protocol over gloo; no kernel ran)"}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,17 +380,29 @@ def main():
     ap.add_argument("--pipelined", action="store_true",
                     help="two batches in flight on two HIP streams (ProposalRoIPipeline) instead of one stream")
     ap.add_argument("--serial", action="store_true", help="one stream (the default; kept for old command lines)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the rank protocol over gloo (launcher, barrier, gather); measures nothing")
     args = ap.parse_args()
     args.serial = not args.pipelined
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args.gpus, sys.argv[1:])
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is used" % (args.gpus, world),
+              file=sys.stderr)
+    if args.dry_run:
+        dry_run(args, world, rank)
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()  # n_gpus of the line = what RCCL reports
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)

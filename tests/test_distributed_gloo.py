@@ -69,3 +69,38 @@ def test_two_rank_shard_and_gather(tmp_path, oracle):
         spans.append(tuple(z["span"]))
     assert spans == [(0, 3), (3, 5)]
     assert ref_c.sum() > 0
+
+
+def _run_bench(cmd, timeout=300):
+    import json
+    import subprocess
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    return r.returncode, [json.loads(l) for l in lines], r.stderr.decode()
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher around it) must run two ranks: rehearsed on CPU with
+    --dry-run (gloo, no kernel).  n_gpus is what the process group reports, the gather ran."""
+    rc, lines, err = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--batch", "3", "--dry-run"])
+    assert rc == 0, err
+    assert len(lines) == 1, "exactly one JSON line (rank 0's)"
+    assert lines[0]["n_gpus"] == 2 and lines[0]["gather_ms"] is not None and lines[0]["dry_run"] is True
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's command shape: torch.distributed.run creates the ranks, --gpus N only names them."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rc, lines, err = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                 "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                                 "--steps", "2", "--batch", "2", "--dry-run"])
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["gather_ms"] is not None
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    rc, lines, err = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--batch", "-1", "--dry-run"])
+    assert rc != 0 and not lines
+    assert "ranks exited with" in err
