@@ -144,6 +144,19 @@ int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, 
                          int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* frcnn_nms_sorted_f32 for callers that cannot allocate device memory.  NO COUNTERPART IN THE REFERENCE: it
+ * exists for callers under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same
+ * arguments, kernels and results, but the round path's workspace is a file-scope device array inside the
+ * library (frcnn_nms_static_scratch_bytes() = 16 MiB, held by every GPU the library runs on until the process
+ * ends) instead of a caller buffer; the call allocates and frees nothing.  Sizes with
+ * frcnn_nms_workspace_bytes(B, max_n) above that maximum are rejected with FRCNN_EINVAL (B = 16 images of
+ * 30,000 boxes or B = 52 of 12,000 fit).  All calls on one GPU share the array: calls that overlap in time
+ * on the same GPU (two streams, two host threads) race -- serialise them or use the workspace form. */
+size_t frcnn_nms_static_scratch_bytes(void);
+int frcnn_nms_sorted_static_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
+                                double iou_threshold, int max_keep, int32_t *keep_out,
+                                int32_t *n_keep_out, void *stream);
+
 /* out[b, j, :] = src[b, idx[b, j], :] for j < count[b], zeros for count[b] <= j < m
  * (proposal[nms_index], RPN/rpn.py:85).  src: (B, n, 4); idx: (B, m); count: (B) or NULL (= m). */
 int frcnn_gather_boxes_f32(const float *src, const int32_t *idx, const int32_t *count, int B, int n,

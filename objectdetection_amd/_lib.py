@@ -39,6 +39,8 @@ SIGNATURES = {
                                                _P]),
     "frcnn_nms_workspace_bytes": (_Z, [_I, _I]),
     "frcnn_nms_sorted_f32": (_I, [_P, _P, _I, _I, _D, _I, _P, _P, _P, _Z, _P]),
+    "frcnn_nms_static_scratch_bytes": (_Z, []),
+    "frcnn_nms_sorted_static_f32": (_I, [_P, _P, _I, _I, _D, _I, _P, _P, _P]),
     "frcnn_gather_boxes_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "frcnn_box_iou_f32": (_I, [_P, _I, _P, _I, _P, _P]),
     "frcnn_iou_label_encode_f32": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),

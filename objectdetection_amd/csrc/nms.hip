@@ -20,6 +20,8 @@
 // equivalent for every fp32 iou.  NaN never suppresses.
 #include <math.h>
 
+#include <mutex>
+
 #include "common.h"
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v)
@@ -580,10 +582,9 @@ static FrcnnThr make_threshold(double thr)
     return th;
 }
 
-extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
-                                    double iou_threshold, int max_keep, int32_t *keep_out,
-                                    int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
-                                    void *stream)
+static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B, int max_n,
+                          double iou_threshold, int max_keep, int32_t *keep_out, int32_t *n_keep_out,
+                          void *workspace, size_t workspace_bytes, void *stream)
 {
     FRCNN_REQUIRE(B >= 0 && max_n >= 0 && max_keep >= 0, "nms: bad shape");
     if (B == 0) return FRCNN_OK;
@@ -637,4 +638,67 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
         FRCNN_CHECK_LAUNCH("nms_round_scan");
     }
     return FRCNN_OK;
+}
+
+extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
+                                    double iou_threshold, int max_keep, int32_t *keep_out,
+                                    int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    return nms_sorted_run(boxes, n_per_image, B, max_n, iou_threshold, max_keep, keep_out, n_keep_out, workspace,
+                          workspace_bytes, stream);
+}
+
+// ---- the entry point that allocates nothing ---------------------------------------------------------
+// For callers that cannot allocate device memory (HIP graph capture, tight serving loops, harnesses that
+// forbid it): the round path's workspace (kept list, one round's tiles, pull words, counters) lives in a
+// file-scope device array instead of a caller buffer.  Every GPU holds its own copy of the array at its own
+// address; `scratch` below is only the host-side stand-in of the symbol, so host code never passes it to a
+// kernel: the device address is looked up once per device (hipGetSymbolAddress, with that device current)
+// and kept in g_scratch_ptr[device].  The NMS kernels need nothing of the workspace cleared (round 0 reads
+// none of it), so a call starts on whatever the previous call left there.  All calls on one GPU share the
+// array: calls that overlap in time on one GPU (two streams, two threads) race.
+#define NMS_STATIC_SCRATCH_BYTES ((size_t)16 << 20)
+static __device__ __align__(256) unsigned char scratch[NMS_STATIC_SCRATCH_BYTES];
+static void *g_scratch_ptr[FRCNN_MAX_DEVICES];
+static std::mutex g_scratch_lock;
+
+static int nms_scratch_address(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    FRCNN_REQUIRE(e == hipSuccess, "nms_static: hipGetDevice failed: %s", hipGetErrorString(e));
+    FRCNN_REQUIRE(dev >= 0 && dev < FRCNN_MAX_DEVICES, "nms_static: device %d not supported (max %d)", dev,
+                  FRCNN_MAX_DEVICES);
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        FRCNN_REQUIRE(e == hipSuccess && p, "nms_static: hipGetSymbolAddress failed on device %d: %s", dev,
+                      hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return FRCNN_OK;
+}
+
+extern "C" size_t frcnn_nms_static_scratch_bytes(void) { return NMS_STATIC_SCRATCH_BYTES; }
+
+extern "C" int frcnn_nms_sorted_static_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
+                                           double iou_threshold, int max_keep, int32_t *keep_out,
+                                           int32_t *n_keep_out, void *stream)
+{
+    FRCNN_REQUIRE(B >= 0 && max_n >= 0 && max_keep >= 0, "nms_static: bad shape");
+    const size_t need = frcnn_nms_workspace_bytes(B, max_n);
+    FRCNN_REQUIRE(need <= NMS_STATIC_SCRATCH_BYTES,
+                  "nms_static: B = %d images of max_n = %d boxes need %zu B of scratch, the built-in array holds %zu B; "
+                  "use frcnn_nms_sorted_f32 with a caller workspace",
+                  B, max_n, need, (size_t)NMS_STATIC_SCRATCH_BYTES);
+    void *ws = nullptr;
+    if (need > 0) {
+        const int rc = nms_scratch_address(&ws);
+        if (rc != FRCNN_OK) return rc;
+    }
+    return nms_sorted_run(boxes, n_per_image, B, max_n, iou_threshold, max_keep, keep_out, n_keep_out, ws, need,
+                          stream);
 }

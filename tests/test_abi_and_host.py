@@ -46,6 +46,11 @@ def test_argument_validation_needs_no_gpu():
     assert lib.frcnn_topk_workspace_bytes(2, 1000, 100) == 2 * 4 * 100 * 4
     assert lib.frcnn_nms_workspace_bytes(1, 128) == 0  # single-launch path needs none
     assert lib.frcnn_nms_workspace_bytes(2, 12000) >= 2 * 12000 * 20
+    # the no-allocation form refuses what its built-in 16 MiB array cannot hold, before any GPU call
+    assert lib.frcnn_nms_static_scratch_bytes() == 16 << 20
+    assert lib.frcnn_nms_workspace_bytes(16, 30000) <= 16 << 20 < lib.frcnn_nms_workspace_bytes(64, 30000)
+    rc = lib.frcnn_nms_sorted_static_f32(null, null, 64, 30000, 0.7, 2000, null, null, null)
+    assert rc == -1 and b"scratch" in lib.frcnn_last_error_string()
 
 
 def test_base_anchors_host_function_matches_reference():
