@@ -186,10 +186,34 @@ class Path:
         return props, n_keep, out, total
 
 
-def cpu_baseline(batch_sample, threads, workload, seconds=10.0):
-    """Times the CPU oracle on `batch_sample` images of the same workload (full path)."""
+def host_cpu():
+    """What the CPU baseline ran on: model name, logical CPUs of the machine, and the threads this process may
+    use -- on a shared GPU box the job owns a SHARE of the machine (OMP_NUM_THREADS / the affinity mask say how
+    much), and oversubscribing it would time the neighbours, not the oracle."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 1
+    env = os.environ.get("OMP_NUM_THREADS")
+    share = int(env) if env and env.isdigit() and int(env) > 0 else affinity
+    return model, os.cpu_count() or 1, affinity, min(share, affinity)
+
+
+def cpu_baseline(batch_sample, workload, seconds=10.0):
+    """Times the CPU oracle on `batch_sample` images of the same workload (full path): passes of
+    `batch_sample` images each, at least 5 and about `seconds` of CPU work; value = median pass."""
     from oracle import oracle as orc
     orc.build()
+    model, machine_cpus, affinity, threads = host_cpu()
     orc.set_threads(threads)
     params = dict(num_pre_nms=PRE_NMS, num_post_nms=POST_NMS, nms_threshold=NMS_THR, proposal_min_size=MIN_SIZE)
     imgs = [synth_image(i, workload) for i in range(batch_sample)]
@@ -200,20 +224,24 @@ def cpu_baseline(batch_sample, threads, workload, seconds=10.0):
         out, _ = orc.multiscale_roi_align([feat[None].numpy()], props, [(IMG_H, IMG_W)], (7, 7), 2)
         return len(props[0]), out
 
-    one(0)  # warm-up
-    t0 = time.perf_counter()
-    rois = done = 0
-    while True:  # a bounded sample: cycle over the images until ~`seconds` of CPU work are on the clock
-        n, _ = one(done % batch_sample)
-        rois += n
-        done += 1
-        dt = time.perf_counter() - t0
-        if done >= batch_sample and dt >= seconds:
-            break
-    return dict(value=done / dt, unit="images/s", cores=threads, kind="port",
-                sample="%d passes over %d images of the same workload (full path incl. RoIAlign C=%d), "
-                       "oracle/frcnn_oracle.c with OpenMP (RoIAlign, IoU rows), %.2f s, %d RoIs"
-                       % (done, batch_sample, C, dt, rois))
+    for i in range(min(2, batch_sample)):  # warm-up 2
+        one(i)
+    passes, rois = [], 0
+    t_all = time.perf_counter()
+    while len(passes) < 5 or (time.perf_counter() - t_all < seconds and len(passes) < 10000):
+        t0 = time.perf_counter()
+        for i in range(batch_sample):
+            rois += one(i)[0]
+        passes.append(time.perf_counter() - t0)
+    total = time.perf_counter() - t_all
+    med = float(np.median(passes))
+    return dict(value=batch_sample / med, unit="images/s", cores=threads, kind="port",
+                cpu_model=model, machine_logical_cpus=machine_cpus, affinity_cpus=affinity, threads_used=threads,
+                threads_note="threads = this job's CPU share (OMP_NUM_THREADS / affinity mask), not the machine's count",
+                passes=len(passes), pass_s_median=med, pass_s_min=float(min(passes)), pass_s_max=float(max(passes)),
+                sample="median of %d passes over %d images of the same workload (full path incl. RoIAlign C=%d), "
+                       "oracle/frcnn_oracle.c with OpenMP (RoIAlign, IoU rows) on %d threads, %.2f s in all, %d RoIs"
+                       % (len(passes), batch_sample, C, threads, total, rois))
 
 
 def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipelined=True):
@@ -474,8 +502,7 @@ def main():
             line["roofline"]["frac_of_measured_fill"] = (line["roofline"]["achieved"] /
                                                          extras["hbm_measured_GBps"]["write_only_fill"])
         if args.cpu_sample > 0 and world == 1:
-            threads = min(os.cpu_count() or 1, 16)
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads, args.workload, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.workload, args.cpu_seconds)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
@@ -526,13 +553,35 @@ def next_rows_microbench(dev):
         return e0.elapsed_time(e1) / reps
 
     res = {}
-    # row 3: batch assembly, 16 images 3x600x1000 -> max side 1000 (scale 1) -> (16,3,608,1024)
+    # row 3: batch assembly, 16 images 3x600x1000 -> max side 1000 (scale 1) -> (16,3,608,1024).  Three figures:
+    # the launch alone (event bracket, preallocated batch), the whole GeneralizedTransform.forward into a reused
+    # batch buffer (wall clock, synchronised), and the same allocating a fresh 120 MB batch per call -- the last
+    # one depends on the state of torch's caching allocator (0.06 ms when it has a block, milliseconds when it
+    # goes to hipMalloc), which is why a caller that cares passes out=.
     images = [torch.rand(3, IMG_H, IMG_W, generator=g).to(dev) for _ in range(B)]
     gt = GeneralizedTransform(600, 1000)
-    ms = timed(lambda: gt(list(images), [None] * B))
+    batch = torch.empty((B, 3, 608, 1024), dtype=torch.float32, device=dev)
+    sizes = [(IMG_H, IMG_W)] * B
+    ms = timed(lambda: ops.resize_pad_batch(images, sizes, batch))
+
+    def wall(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    wall_reuse = wall(lambda: gt(list(images), [None] * B, out=batch))
+    wall_alloc = wall(lambda: gt(list(images), [None] * B))
     nbytes = B * 3 * (IMG_H * IMG_W + 608 * 1024) * 4
     res["batch_assembly"] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / ms / 1e6,
-                             "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "launches": (B + 31) // 32}
+                             "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "launches": (B + 31) // 32,
+                             "what": "resize_pad_batch launch alone, preallocated batch, HIP events",
+                             "forward_wall_ms_reused_out": wall_reuse, "forward_wall_ms_fresh_batch": wall_alloc}
+    del batch
     # row 2: RPN loss tail, 256 sampled anchors per image out of A; forward + gradients in one launch (+2 memsets)
     scores = torch.randn(B, A, generator=g).to(dev)
     regs = torch.randn(B, A, 4, generator=g).to(dev)
@@ -746,13 +795,16 @@ def roi_pool_microbench(path, dev):
 
 
 def nms_microbench(path, dev):
-    """'NMS ms/img at 20k anchors': NMS alone (mask + scan) on n = 12,000 pre-sorted boxes per image,
-    batch 16, three box sets: realistic, bug-compatible decode output, lattice."""
+    """'NMS ms/img at 20k anchors' (SURVEY.md 8d): NMS alone on pre-sorted boxes, batch 16, keep <= 2,000, three box
+    sets -- realistic (spread over the image), bug-compatible (what the reference's decode, quirk Q1, makes of
+    config 1's Gaussian deltas: everything lands on the origin) and lattice (disjoint: nothing is suppressed) --
+    at n = 12,000 (the pre-NMS count), 20,646 (every anchor of the 37 x 62 map) and 30,000 (config 5's pre-NMS
+    count; the bug-compatible set exists only up to the map's 20,646 anchors)."""
     ops = path.ops
     rng = np.random.default_rng(0)
-    n, B = PRE_NMS, 16
+    B = 16
 
-    def realistic():
+    def realistic(n):
         cx, cy = rng.uniform(0, IMG_W, n), rng.uniform(0, IMG_H, n)
         w, h = 16 * 2 ** rng.uniform(0, 5, n), 16 * 2 ** rng.uniform(0, 5, n)
         b = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
@@ -760,26 +812,41 @@ def nms_microbench(path, dev):
         b[:, 1::2] = b[:, 1::2].clip(0, IMG_H)
         return b.astype(np.float32)
 
-    def lattice():
+    def lattice(n):
         side = int(np.ceil(np.sqrt(n)))
         ys, xs = np.divmod(np.arange(n), side)
         return np.stack([xs * 5.0, ys * 5.0, xs * 5.0 + 4, ys * 5.0 + 4], 1).astype(np.float32)
 
-    sets = {"realistic": torch.as_tensor(np.stack([realistic() for _ in range(B)])).to(dev),
-            "lattice": torch.as_tensor(np.stack([lattice() for _ in range(B)])).to(dev)}
+    cls, reg, feat = (t.to(dev) for t in make_batch(0, B, "gaussian"))
+    anchors = path.anchors(B, feat)
+    scores, deltas = ops.rpn_flatten([cls], [reg])
+
+    def bug_compatible(n):
+        top_val, top_idx = ops.topk_desc(scores, n)
+        boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
+        return boxes, count
+
     res = {}
-    for name, boxes in sets.items():
-        for _ in range(3):
-            keep, nk = ops.nms_sorted(boxes, None, NMS_THR, POST_NMS)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        reps = 10
-        for _ in range(reps):
-            keep, nk = ops.nms_sorted(boxes, None, NMS_THR, POST_NMS)
-        e1.record()
-        torch.cuda.synchronize()
-        res[name] = {"ms_per_img": e0.elapsed_time(e1) / reps / B, "keeps_mean": float(nk.float().mean())}
-    return {"nms_ms_per_img_n12000_batch16": res}
+    for n in (PRE_NMS, A, 30000):
+        sets = {"realistic": (torch.as_tensor(np.stack([realistic(n) for _ in range(B)])).to(dev), None),
+                "lattice": (torch.as_tensor(np.stack([lattice(n) for _ in range(B)])).to(dev), None)}
+        if n <= A:
+            sets["bug_compatible"] = bug_compatible(n)
+        for name, (boxes, count) in sets.items():
+            for _ in range(3):
+                keep, nk = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reps = 10
+            for _ in range(reps):
+                keep, nk = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
+            e1.record()
+            torch.cuda.synchronize()
+            res.setdefault("n%d" % n, {})[name] = {"ms_per_img": e0.elapsed_time(e1) / reps / B,
+                                                   "keeps_mean": float(nk.float().mean())}
+    out = {"nms_ms_per_img_batch16": res}
+    out["nms_ms_per_img_n12000_batch16"] = res["n%d" % PRE_NMS]  # (the key round 1's line carried)
+    return out
 
 
 if __name__ == "__main__":

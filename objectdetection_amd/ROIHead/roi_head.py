@@ -33,6 +33,9 @@ class ROIHead(Module):
         self.nms_threshold = params['nms_threshold']
         self.num_post_nms = params['num_post_nms']
         self.force_eval = params.get('force_eval', True)
+        # what the last training forward sampled (roi_head.py:113-124): per image the random_index (negatives
+        # first) and the gathered labels / encodings / proposals -- observable for the sampling-order tests
+        self.last_sampled = None
 
     # -- proposal targets: roi_head.py:99-110, batched -------------------------------------------
     def proposal_targets(self, list_rpn_proposals, list_targets, device):
@@ -76,6 +79,7 @@ class ROIHead(Module):
             pos_cnt = torch.bincount(pos_all[:, 0], minlength=n_img).tolist()
             neg_cnt = torch.bincount(neg_all[:, 0], minlength=n_img).tolist()
             pos_off = neg_off = 0
+            self.last_sampled = []
             for i, (proposal, (cls_label, reg_label)) in enumerate(zip(list_rpn_proposals, targets)):
                 pos_index = pos_all[pos_off:pos_off + pos_cnt[i], 1]
                 neg_index = neg_all[neg_off:neg_off + neg_cnt[i], 1]
@@ -87,6 +91,8 @@ class ROIHead(Module):
                 list_cls_label.append(cls_label[random_index])
                 list_reg_label.append(reg_label[random_index])
                 list_proposals.append(proposal[random_index])
+                self.last_sampled.append({"random_index": random_index, "cls_label": list_cls_label[-1],
+                                          "reg_label": list_reg_label[-1], "proposal": list_proposals[-1]})
             list_rpn_proposals = list_proposals
 
         dict_feature = dict(zip([str(i + 1) for i in range(len(list_features))], list_features))

@@ -32,6 +32,9 @@ class RPN(Module):
         # workgroups per image for the top-k (ops.topk_desc): 0 = the library's choice; set to 1 when the
         # proposal stages run beside RoIAlign on another stream (pipeline.ProposalRoIPipeline)
         self.topk_max_slices = 0
+        # what the last training forward sampled (rpn.py:115-127): per image the random_index (negatives first)
+        # and the gathered cls / reg labels -- observable so that the sampling order can be checked
+        self.last_sampled = None
 
     # -- anchors ---------------------------------------------------------------------------------
     def _flat_anchors(self, batch_image_info, list_features):
@@ -105,7 +108,7 @@ class RPN(Module):
             pos_all = torch.nonzero(torch.eq(labels, 1))
             neg_cnt = torch.bincount(neg_all[:, 0], minlength=batch_size).tolist()
             pos_cnt = torch.bincount(pos_all[:, 0], minlength=batch_size).tolist()
-            list_index = []
+            list_index, sampled = [], []
             neg_off = pos_off = 0
             for b in range(batch_size):
                 neg_index = neg_all[neg_off:neg_off + neg_cnt[b], 1]
@@ -116,6 +119,9 @@ class RPN(Module):
                                                              pos_index.size(0), neg_index.size(0))
                 random_index = torch.cat([neg_index[neg_factor.to(device)], pos_index[pos_factor.to(device)]])
                 list_index.append(random_index + b * A)
+                sampled.append({"random_index": random_index, "cls_label": labels[b][random_index],
+                                "reg_label": reg_labels[b][random_index]})
+            self.last_sampled = sampled
             # rpn.py:123-137: the four gathers, BCE-with-logits and smooth-L1 (Q7) are one launch, with
             # gradients to the dense head outputs (ops.RpnSampledLoss)
             cls_loss, reg_loss = ops.RpnSampledLoss.apply(scores, regs, labels, reg_labels, torch.cat(list_index))

@@ -29,20 +29,30 @@ def canvas_size(sizes, divide_size):
     return math.ceil(max_height / divide_size) * divide_size, math.ceil(max_width / divide_size) * divide_size
 
 
-def batched_images(images, divide_size):
-    """utils.py:339-372 -- zero-pad a list of (C,h,w) images to one (B,C,H,W) batch."""
+def batched_images(images, divide_size, out=None):
+    """utils.py:339-372 -- zero-pad a list of (C,h,w) images to one (B,C,H,W) batch.  `out` (not in the
+    reference): a contiguous fp32 batch of exactly that shape to write into instead of a new tensor."""
     sizes = [(int(im.size(1)), int(im.size(2))) for im in images]
-    return _assemble(images, sizes, divide_size)
+    return _assemble(images, sizes, divide_size, out)
 
 
-def _assemble(images, out_sizes, divide_size):
+def _assemble(images, out_sizes, divide_size, out=None):
     canvas_h, canvas_w = canvas_size(out_sizes, divide_size)
     channels = int(images[0].size(0))
     for (h, w), im in zip(out_sizes, images):
         if h > canvas_h or w > canvas_w or int(im.size(0)) != channels:
             raise ValueError("a (%d, %d, %d) image does not fit the (%d, %d, %d) canvas the reference computes "
                              "(utils.py:353-357: the elif skips widths)" % (im.size(0), h, w, channels, canvas_h, canvas_w))
-    batch = torch.empty((len(images), channels, canvas_h, canvas_w), dtype=torch.float32, device=images[0].device)
+    shape = (len(images), channels, canvas_h, canvas_w)
+    if out is not None:
+        # a caller that assembles same-shaped batches step after step keeps one buffer: a fresh ~100 MB tensor per
+        # call can send torch's caching allocator to hipMalloc (milliseconds; the kernel itself is ~0.06 ms)
+        if tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() \
+                or out.device != images[0].device:
+            raise ValueError("out must be a contiguous fp32 %s tensor on %s" % (shape, images[0].device))
+        batch = out
+    else:
+        batch = torch.empty(shape, dtype=torch.float32, device=images[0].device)
     ops.resize_pad_batch(images, out_sizes, batch)   # one launch for the list (per 32 images)
     return batch
 
@@ -53,7 +63,8 @@ class GeneralizedTransform(Module):
         self.min_size = min_size
         self.max_size = max_size
 
-    def forward(self, images, targets):
+    def forward(self, images, targets, out=None):
+        """`out` (not in the reference): batch buffer to reuse, see batched_images."""
         out_sizes = []
         for i in range(len(images)):
             image, target = images[i], targets[i]
@@ -71,4 +82,4 @@ class GeneralizedTransform(Module):
                 ratio_width = torch.tensor([width / new_w], dtype=box.dtype, device=box.device)
                 target['box'] = torch.cat([box[:, 0] * ratio_width, box[:, 1] * ratio_height,
                                            box[:, 2] * ratio_width, box[:, 3] * ratio_height])       # :76-81
-        return _assemble(images, out_sizes, 32), targets
+        return _assemble(images, out_sizes, 32, out), targets

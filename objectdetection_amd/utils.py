@@ -20,10 +20,11 @@ __all__ = ["box_iou", "box_deviation", "box_regression", "remove_small_box", "bo
            "get_sampling_factor", "smooth_l1_loss", "batched_images", "loc2bbox", "bbox2loc", "bbox_iou"]
 
 
-def batched_images(images, divide_size):
-    """utils.py:339-372 -- zero-pad a list of (C,h,w) images into one (B,C,H,W) batch (on the device)."""
+def batched_images(images, divide_size, out=None):
+    """utils.py:339-372 -- zero-pad a list of (C,h,w) images into one (B,C,H,W) batch (on the device);
+    `out` (an extension): a batch buffer of that shape to reuse."""
     from .generalized_transform import batched_images as impl
-    return impl(images, divide_size)
+    return impl(images, divide_size, out)
 
 
 def box_iou(box_1, box_2):

@@ -19,6 +19,10 @@ reference's own functions produced for them:
   code/FasterRCNN/generalized_transform.py GeneralizedTransform.forward,
   code/FasterRCNN/utils.py                 batched_images             -> transform.npz
   code/FasterRCNN/utils.py                 get_sampling_factor        -> sampling.npz
+  RPN/rpn.py:90-137 and ROIHead/roi_head.py:99-124,141-152 (the training
+  halves: labels, encodings, get_sampling_factor under torch.manual_seed,
+  negatives-first concat, gathers, losses) replayed line by line with the
+  reference's utils functions                                          -> train_sampling.npz
   RPN/rpn.py:55-83 call sequence replayed with the reference's utils
   functions and torch.topk (rpn.py itself cannot be imported: it needs
   torchvision, which is absent)                                        -> rpn_stages.npz
@@ -393,6 +397,120 @@ def gen_rpn_stages():
     save("rpn_stages.npz", **out)
 
 
+def gen_train_sampling():
+    """the ORCHESTRATION of the two training halves.  rpn.py and roi_head.py cannot be
+    imported (torchvision), so their training branches are replayed here statement by statement with the
+    reference's own utils functions on CPU under a fixed torch.manual_seed: per image tagging_box,
+    box_deviation, where(), get_sampling_factor (positives drawn first, utils.py:310-311), the
+    NEGATIVES-FIRST concat (rpn.py:122, roi_head.py:121), the gathers and the two losses."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(8675309)
+    out = {}
+    # ---------------- RPN.forward training half: rpn.py:90-137
+    info, fsz = (2, 192, 320), [(12, 20), (6, 10)]
+    num_sample, pos_fraction, neg_thr, pos_thr, seed = 64, 0.5, 0.3, 0.7, 2024
+    ag = AnchorGenerator()
+    list_anchors = ag(info, [torch.zeros(info[0], 1, h, w) for h, w in fsz])
+    list_cls = [torch.randn(info[0], 9, h, w, generator=g) for h, w in fsz]
+    list_regs = [torch.randn(info[0], 36, h, w, generator=g) * 0.3 for h, w in fsz]
+    flat = torch.cat(list_anchors, dim=1).flatten(1, 2)[0]
+    # ground truth = jittered copies of anchors (so that IoU > 0.7 positives exist): 10 boxes for image 0
+    # (more positives than num_sample * pos_fraction), 2 for image 1 (fewer: quirk Q9, no negative top-up)
+    list_targets = []
+    for m, lo, hi in ((10, 33, 10 ** 6), (2, 1, 31)):
+        while True:  # draw until the image has the wanted number of positives
+            pick = flat[torch.randperm(flat.shape[0], generator=g)[:m]]
+            gt = pick + torch.randn(m, 4, generator=g) * (1.5 if m > 2 else 8.0)
+            n_pos = int((R.tagging_box(flat, gt, neg_thr, pos_thr) == 1).sum())
+            if lo <= n_pos <= hi:
+                break
+        list_targets.append({"box": gt.tolist()})
+    batch_size = info[0]
+    l_cls = [c.permute(0, 2, 3, 1).flatten(1, 3) for c in list_cls]                                  # rpn.py:90-91
+    l_regs = [r.permute(0, 2, 3, 1).flatten(1, 2).reshape(batch_size, -1, 4) for r in list_regs]     # rpn.py:92-93
+    anchors = torch.cat(list_anchors, dim=1).flatten(1, 2)                                           # rpn.py:96
+    scores = torch.cat(l_cls, dim=1)
+    regs = torch.cat(l_regs, dim=1)
+    torch.manual_seed(seed)
+    l_reg_label, l_reg_pred, l_cls_label, l_cls_pred = [], [], [], []
+    for b, (anchor, score, reg, target) in enumerate(zip(anchors, scores, regs, list_targets)):      # rpn.py:105
+        ground_truth = torch.tensor(target["box"], dtype=torch.float32)
+        cls_label = R.tagging_box(anchor, ground_truth, neg_thr, pos_thr)
+        reg_label = R.box_deviation(anchor, ground_truth)
+        neg_index = torch.where(torch.eq(cls_label, 0))[0]
+        pos_index = torch.where(torch.eq(cls_label, 1))[0]
+        pos_factor, neg_factor = R.get_sampling_factor(num_sample, pos_fraction, pos_index.size(0), neg_index.size(0))
+        random_index = torch.cat([neg_index[neg_factor], pos_index[pos_factor]])                     # rpn.py:122
+        l_reg_label.append(reg_label[random_index])
+        l_cls_label.append(cls_label[random_index])
+        l_reg_pred.append(reg[random_index])
+        l_cls_pred.append(score[random_index])
+        out[f"rpn.b{b}.gt"] = ground_truth.numpy()
+        out[f"rpn.b{b}.n_pos_neg"] = np.asarray([pos_index.size(0), neg_index.size(0)])
+        out[f"rpn.b{b}.random_index"] = random_index.numpy()
+        out[f"rpn.b{b}.cls_label"] = l_cls_label[-1].numpy()
+        out[f"rpn.b{b}.reg_label"] = l_reg_label[-1].numpy()
+    cls_loss = F.binary_cross_entropy_with_logits(torch.cat(l_cls_pred), torch.cat(l_cls_label))     # rpn.py:136
+    reg_loss = R.smooth_l1_loss(torch.cat(l_reg_pred), torch.cat(l_reg_label))                       # rpn.py:137
+    assert out["rpn.b0.n_pos_neg"][0] > num_sample * pos_fraction > out["rpn.b1.n_pos_neg"][0] > 0
+    out.update({"rpn.info": np.asarray(info), "rpn.fsz": np.asarray(fsz), "rpn.seed": np.asarray(seed),
+                "rpn.params": np.asarray([num_sample, pos_fraction, neg_thr, pos_thr], np.float64),
+                "rpn.cls_loss": cls_loss.numpy(), "rpn.reg_loss": reg_loss.numpy()})
+    for l in range(len(fsz)):
+        out[f"rpn.cls{l}"] = list_cls[l].numpy()
+        out[f"rpn.reg{l}"] = list_regs[l].numpy()
+    # ---------------- ROIHead.forward training half: roi_head.py:99-124, 141-152
+    num_sample, pos_fraction, neg_thr, pos_thr, seed = 64, 0.25, 0.5, 0.5, 77
+    weights = [10.0, 10.0, 5.0, 5.0]
+    Kc = 21
+    list_props, list_targets = [], []
+    for n_prop, m, n_near in ((300, 6, 60), (180, 2, 5)):
+        gt = rand_gt(g, m, W=320.0, H=192.0) * torch.tensor([0.3, 0.3, 0.3, 0.3]) + torch.tensor([20.0, 20.0, 60.0, 60.0])
+        xy = torch.rand(n_prop, 2, generator=g) * torch.tensor([260.0, 150.0])
+        wh = torch.rand(n_prop, 2, generator=g) * 80 + 4
+        props = torch.cat([xy, xy + wh], 1)
+        near = gt[torch.randint(0, m, (n_near,), generator=g)] + torch.randn(n_near, 4, generator=g) * 2.0
+        props[torch.randperm(n_prop, generator=g)[:n_near]] = near
+        list_props.append(props)
+        list_targets.append({"class": torch.randint(1, Kc, (m,), generator=g).float().tolist(), "box": gt.tolist()})
+    torch.manual_seed(seed)
+    l_cls_label, l_reg_label, l_props = [], [], []
+    for b, (proposal, target) in enumerate(zip(list_props, list_targets)):                           # roi_head.py:99
+        labels = torch.as_tensor(target["class"])
+        ground_truth = torch.as_tensor(target["box"], dtype=torch.float32)
+        cls_label = R.tagging_box(proposal, ground_truth, neg_thr, pos_thr, labels)
+        reg_label = R.box_deviation(proposal, ground_truth, weights)
+        pos_index = torch.where(torch.gt(cls_label, 0))[0]
+        neg_index = torch.where(torch.eq(cls_label, 0))[0]
+        pos_factor, neg_factor = R.get_sampling_factor(num_sample, pos_fraction, pos_index.size(0), neg_index.size(0))
+        random_index = torch.cat([neg_index[neg_factor], pos_index[pos_factor]])                     # roi_head.py:121
+        l_cls_label.append(cls_label[random_index])
+        l_reg_label.append(reg_label[random_index])
+        l_props.append(proposal[random_index])
+        out[f"roi.b{b}.proposals"] = proposal.numpy()
+        out[f"roi.b{b}.gt"] = ground_truth.numpy()
+        out[f"roi.b{b}.class"] = labels.numpy()
+        out[f"roi.b{b}.n_pos_neg"] = np.asarray([pos_index.size(0), neg_index.size(0)])
+        out[f"roi.b{b}.random_index"] = random_index.numpy()
+        out[f"roi.b{b}.cls_label"] = l_cls_label[-1].numpy()
+        out[f"roi.b{b}.reg_label"] = l_reg_label[-1].numpy()
+        out[f"roi.b{b}.sampled_proposals"] = l_props[-1].numpy()
+    assert out["roi.b0.n_pos_neg"][0] > num_sample * pos_fraction > out["roi.b1.n_pos_neg"][0] > 0
+    cls_label = torch.cat(l_cls_label)                                                               # roi_head.py:141
+    reg_label = torch.cat(l_reg_label)
+    N = cls_label.shape[0]
+    predict_cls = torch.randn(N, Kc, generator=g) * 2        # what the (out of scope) dense heads would emit
+    predict_reg = (torch.randn(N, Kc * 4, generator=g) * 0.5).view(N, -1, 4)
+    ce = F.cross_entropy(predict_cls, cls_label.long())                                              # roi_head.py:144
+    pos_index = torch.where(torch.gt(cls_label, 0))[0]
+    rl = R.smooth_l1_loss(predict_reg[pos_index, cls_label[pos_index].long()], reg_label[pos_index])  # :147-152
+    out.update({"roi.seed": np.asarray(seed), "roi.weights": np.asarray(weights, np.float32),
+                "roi.params": np.asarray([num_sample, pos_fraction, neg_thr, pos_thr], np.float64),
+                "roi.predict_cls": predict_cls.numpy(), "roi.predict_reg": predict_reg.reshape(N, -1).numpy(),
+                "roi.cls_loss": ce.numpy(), "roi.reg_loss": rl.numpy()})
+    save("train_sampling.npz", **out)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not present: goldens can only be generated in the build container")
@@ -404,3 +522,4 @@ if __name__ == "__main__":
     gen_transform()
     gen_sampling()
     gen_rpn_stages()
+    gen_train_sampling()
