@@ -73,6 +73,11 @@ def load():
         raise FrcnnError(
             "libfrcnn_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # torch first: its wheel carries its own copy of the HIP runtime (torch/lib/libamdhip64.so, soname
+    # libamdhip64.so.7, the name this library needs).  Loaded after torch, libfrcnn_hip.so binds to that copy
+    # and shares torch's device state and streams; loaded before it, the system copy under /opt/rocm comes in
+    # as a SECOND runtime in the process, and whichever initialises second finds "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
