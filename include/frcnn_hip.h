@@ -213,6 +213,18 @@ int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W, c
                                 float spatial_scale, int sampling_ratio, int level, int n_levels,
                                 int k_min, int k_max, float *out, int32_t *total_out, void *stream);
 
+/* Backward of frcnn_roi_align_batched_f32 with respect to `feat`: what torch autograd runs through
+ * torchvision's MultiScaleRoIAlign at ROIHead/roi_pooling.py:51-53 / ROIHead/roi_head.py:127-130 (the reference's
+ * RoI losses train the backbone through the pooling).  Same arguments as the forward pass of one level;
+ * grad_out: (>= sum(count), C, pooled_h, pooled_w) in the forward's row order; grad_feat: (B, C, H, W), written
+ * in full (zeros where no RoI of this level reaches).  Every sample sends grad * w / (sampling_ratio^2) to its
+ * four taps (torchvision roi_align_backward); boxes get no gradient.  The sum order over RoIs is not fixed
+ * (LDS / global float atomics), as in torchvision. */
+int frcnn_roi_align_batched_backward_f32(const float *grad_out, int B, int C, int H, int W,
+                                         const float *props, const int32_t *count, int P, int pooled_h,
+                                         int pooled_w, float spatial_scale, int sampling_ratio, int level,
+                                         int n_levels, int k_min, int k_max, float *grad_feat, void *stream);
+
 /* torchvision roi_pool (max) -- north_star extra, not called by the reference.
  * out: (K,C,ph,pw) fp32; argmax: (K,C,ph,pw) int32 flat index h*W+w, -1 for an empty bin. */
 int frcnn_roi_pool_f32(const float *feat, int B, int C, int H, int W, const float *rois, int K,

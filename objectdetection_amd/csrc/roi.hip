@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "roi_common.h"
 
 // ---- roi list ---------------------------------------------------------------------------------
 // rois[off[b] + j] = [b, props[b, j, :]] for j < count[b]; one 1024-thread block, B <= 4096.
@@ -88,49 +89,6 @@ extern "C" int frcnn_level_map_f32(const float *rois, const int32_t *n_rois, int
 }
 
 // ---- RoIAlign ---------------------------------------------------------------------------------
-// One bilinear sample: 4 tap offsets inside the channel plane + 4 weights (zero when the sample
-// falls outside [-1, H] x [-1, W]).  Mirrors torchvision's pre_calc_for_bilinear_interpolate.
-struct __align__(16) Sample {
-    int p1, p2, p3, p4;
-    float w1, w2, w3, w4;
-};
-
-__device__ __forceinline__ Sample make_sample(float y, float x, int H, int W)
-{
-    Sample s;
-    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
-        s.p1 = s.p2 = s.p3 = s.p4 = 0;
-        s.w1 = s.w2 = s.w3 = s.w4 = 0.0f;
-        return s;
-    }
-    if (y <= 0.0f) y = 0.0f;
-    if (x <= 0.0f) x = 0.0f;
-    int y_low = (int)y, x_low = (int)x, y_high, x_high;
-    if (y_low >= H - 1) {
-        y_high = y_low = H - 1;
-        y = (float)y_low;
-    } else {
-        y_high = y_low + 1;
-    }
-    if (x_low >= W - 1) {
-        x_high = x_low = W - 1;
-        x = (float)x_low;
-    } else {
-        x_high = x_low + 1;
-    }
-    float ly = y - (float)y_low, lx = x - (float)x_low;
-    float hy = 1.0f - ly, hx = 1.0f - lx;
-    s.p1 = y_low * W + x_low;
-    s.p2 = y_low * W + x_high;
-    s.p3 = y_high * W + x_low;
-    s.p4 = y_high * W + x_high;
-    s.w1 = hy * hx;
-    s.w2 = hy * lx;
-    s.w3 = ly * hx;
-    s.w4 = ly * lx;
-    return s;
-}
-
 // One bilinear sample from a plane in global memory.  The low / high taps of a row are neighbours,
 // so each row is ONE 8-byte load (the kernels that gather through L1 are bound by the number of
 // tap loads); at the right edge, where both taps are the last pixel, the pair starts one pixel
@@ -241,17 +199,6 @@ extern "C" int frcnn_roi_align_f32(const float *feat, int B, int C, int H, int W
 // sees the feature map once plus the output stream.  A wave takes one whole RoI at a time with
 // lane = bin, so each channel store is one 196-byte run and the 16 stores of an iteration fill a
 // contiguous 3136-byte piece of the (K, C, 7, 7) output.
-
-__device__ __forceinline__ int map_level(float4 p, int k_min, int k_max)
-{
-    float area = (p.z - p.x) * (p.w - p.y);
-    float s = sqrtf(area);
-    float t = floorf((4.0f + log2f(s / 224.0f)) + 1e-6f);
-    if (!(t == t)) return -1;
-    t = t < (float)k_min ? (float)k_min : t;
-    t = t > (float)k_max ? (float)k_max : t;
-    return (int)t - k_min;
-}
 
 struct AxisSample { // one 1-D bilinear sample: taps lo/hi with weights (zero when out of range)
     int lo, hi;

@@ -642,6 +642,71 @@ def infer_scale(feature_hw, image_hw):
     return scales[0]
 
 
+def _roi_align_levels(cfg, props, count, feats):
+    """Forward of every level: (out (B*P, C, oh, ow), total (1) int32)."""
+    output_size, sampling_ratio, scales, k_min, k_max = cfg
+    B, P = props.shape[0], props.shape[1]
+    C = feats[0].shape[1]
+    dev = props.device
+    out = torch.empty((B * P, C) + tuple(output_size), dtype=torch.float32, device=dev)
+    total = torch.empty((1,), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        for l, (f, s) in enumerate(zip(feats, scales)):
+            f = _f32c(f)
+            if f.shape[0] != B or f.shape[1] != C:
+                raise ValueError("feature map %d has shape %s, expected (%d,%d,h,w)" % (l, tuple(f.shape), B, C))
+            rc = lib.frcnn_roi_align_batched_f32(
+                _ptr(f), B, C, f.shape[2], f.shape[3], _ptr(props), _ptr(count), P, output_size[0],
+                output_size[1], float(s), sampling_ratio, l, len(feats), k_min, k_max,
+                _ptr(out), _ptr(total), _stream())
+            _lib.check(rc, "roi_align_batched")
+    return out, total
+
+
+def roi_align_levels_backward(cfg, props, count, grad_out, feat_shapes, wanted=None):
+    """Gradients of _roi_align_levels with respect to each feature map (None where not wanted)."""
+    output_size, sampling_ratio, scales, k_min, k_max = cfg
+    B, P = props.shape[0], props.shape[1]
+    grad_out = _f32c(grad_out)
+    grads = []
+    lib = _lib.load()
+    with torch.cuda.device(props.device):
+        for l, (shape, s) in enumerate(zip(feat_shapes, scales)):
+            if wanted is not None and not wanted[l]:
+                grads.append(None)
+                continue
+            g = torch.empty(tuple(shape), dtype=torch.float32, device=props.device)
+            rc = lib.frcnn_roi_align_batched_backward_f32(
+                _ptr(grad_out), B, shape[1], shape[2], shape[3], _ptr(props), _ptr(count), P, output_size[0],
+                output_size[1], float(s), sampling_ratio, l, len(feat_shapes), k_min, k_max, _ptr(g), _stream())
+            _lib.check(rc, "roi_align_batched_backward")
+            grads.append(g)
+    return grads
+
+
+class _RoIAlignLevels(torch.autograd.Function):
+    """MultiScaleRoIAlign over padded proposals, differentiable in the feature maps: forward and backward are
+    the HIP kernels (ROIHead/roi_head.py:127-130 under autograd).  Boxes get no gradient, as in torchvision."""
+
+    @staticmethod
+    def forward(ctx, cfg, props, count, *feats):
+        ctx.cfg = cfg
+        ctx.feat_shapes = [tuple(f.shape) for f in feats]
+        ctx.save_for_backward(props, count) if count is not None else ctx.save_for_backward(props)
+        ctx.has_count = count is not None
+        out, total = _roi_align_levels(cfg, props, count, feats)
+        ctx.mark_non_differentiable(total)
+        return out, total
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_total):
+        saved = ctx.saved_tensors
+        props, count = (saved[0], saved[1]) if ctx.has_count else (saved[0], None)
+        grads = roi_align_levels_backward(ctx.cfg, props, count, grad_out, ctx.feat_shapes, ctx.needs_input_grad[3:])
+        return (None, None, None) + tuple(grads)
+
+
 class MultiScaleRoIAlign(torch.nn.Module):
     """torchvision.ops.MultiScaleRoIAlign(featmap_names, output_size, sampling_ratio) as the
     reference uses it (ROIHead/roi_pooling.py:44-53): FPN level mapper + RoIAlign per level.
@@ -671,24 +736,12 @@ class MultiScaleRoIAlign(torch.nn.Module):
         return feats, scales, k_min, k_max
 
     def _pool_padded(self, feats, scales, k_min, k_max, props, count):
-        """One batched launch per level over zero-padded proposals; rows compacted in image order."""
-        B, P = props.shape[0], props.shape[1]
-        C = feats[0].shape[1]
-        dev = props.device
-        out = torch.empty((B * P, C) + self.output_size, dtype=torch.float32, device=dev)
-        total = torch.empty((1,), dtype=torch.int32, device=dev)
-        lib = _lib.load()
-        with torch.cuda.device(dev):
-            for l, (f, s) in enumerate(zip(feats, scales)):
-                f = _f32c(f)
-                if f.shape[0] != B or f.shape[1] != C:
-                    raise ValueError("feature map %d has shape %s, expected (%d,%d,h,w)" % (l, tuple(f.shape), B, C))
-                rc = lib.frcnn_roi_align_batched_f32(
-                    _ptr(f), B, C, f.shape[2], f.shape[3], _ptr(props), _ptr(count), P, self.output_size[0],
-                    self.output_size[1], float(s), int(self.sampling_ratio), l, len(feats), int(k_min), int(k_max),
-                    _ptr(out), _ptr(total), _stream())
-                _lib.check(rc, "roi_align_batched")
-        return out, total
+        """One batched launch per level over zero-padded proposals; rows compacted in image order.
+        Differentiable with respect to the feature maps (as torchvision's op is) when any of them requires grad."""
+        cfg = (self.output_size, int(self.sampling_ratio), tuple(float(s) for s in scales), int(k_min), int(k_max))
+        if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+            return _RoIAlignLevels.apply(cfg, props, count, *feats)
+        return _roi_align_levels(cfg, props, count, feats)
 
     def forward(self, x, boxes, image_shapes):
         feats, scales, k_min, k_max = self._levels(x, image_shapes)

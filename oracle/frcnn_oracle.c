@@ -577,6 +577,72 @@ void orc_roi_align(const float *feat, int B, int C, int H, int W, const float *r
     }
 }
 
+/* Backward of roi_align above with respect to `feat`, as torchvision's roi_align_backward kernel defines
+ * it (what autograd runs through ROIHead/roi_pooling.py:51-53 when the RoI losses train the backbone):
+ * every sample of a bin sends grad * w_k / count to its four taps; samples outside [-1, H] x [-1, W] send
+ * nothing; rois get no gradient.  grad_feat (B, C, H, W) is ACCUMULATED into (the caller zeroes it; the
+ * multi-level wrapper calls once per level with `sel`).  Accumulation order: RoI by RoI in fp32. */
+void orc_roi_align_backward(const float *grad_out, int B, int C, int H, int W, const float *rois, int K,
+                            int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                            const int32_t *sel, int sel_value, float *grad_feat)
+{
+    (void)B;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int c = 0; c < C; ++c) { /* one thread per channel: no two threads add into the same plane */
+        for (int r = 0; r < K; ++r) {
+            if (sel && sel[r] != sel_value) continue;
+            const float *roi = rois + 5 * r;
+            int b = (int)roi[0];
+            float roi_start_w = roi[1] * spatial_scale;
+            float roi_start_h = roi[2] * spatial_scale;
+            float roi_width = roi[3] * spatial_scale - roi_start_w;
+            float roi_height = roi[4] * spatial_scale - roi_start_h;
+            roi_width = roi_width > 1.0f ? roi_width : 1.0f;
+            roi_height = roi_height > 1.0f ? roi_height : 1.0f;
+            float bin_h = roi_height / (float)pooled_h;
+            float bin_w = roi_width / (float)pooled_w;
+            int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
+            int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
+            float count = (float)(grid_h * grid_w > 1 ? grid_h * grid_w : 1);
+            float *g = grad_feat + ((size_t)b * C + c) * H * W;
+            const float *go = grad_out + ((size_t)r * C + c) * pooled_h * pooled_w;
+            for (int ph = 0; ph < pooled_h; ++ph)
+                for (int pw = 0; pw < pooled_w; ++pw) {
+                    float gbin = go[ph * pooled_w + pw];
+                    for (int iy = 0; iy < grid_h; ++iy) {
+                        float y = roi_start_h + (float)ph * bin_h + ((float)iy + 0.5f) * bin_h / (float)grid_h;
+                        for (int ix = 0; ix < grid_w; ++ix) {
+                            float x = roi_start_w + (float)pw * bin_w + ((float)ix + 0.5f) * bin_w / (float)grid_w;
+                            float yy = y;
+                            if (yy < -1.0f || yy > (float)H || x < -1.0f || x > (float)W) continue;
+                            if (yy <= 0.0f) yy = 0.0f;
+                            if (x <= 0.0f) x = 0.0f;
+                            int y_low = (int)yy, x_low = (int)x, y_high, x_high;
+                            if (y_low >= H - 1) {
+                                y_high = y_low = H - 1;
+                                yy = (float)y_low;
+                            } else {
+                                y_high = y_low + 1;
+                            }
+                            if (x_low >= W - 1) {
+                                x_high = x_low = W - 1;
+                                x = (float)x_low;
+                            } else {
+                                x_high = x_low + 1;
+                            }
+                            float ly = yy - (float)y_low, lx = x - (float)x_low;
+                            float hy = 1.0f - ly, hx = 1.0f - lx;
+                            g[y_low * W + x_low] += gbin * (hy * hx) / count;
+                            g[y_low * W + x_high] += gbin * (hy * lx) / count;
+                            g[y_high * W + x_low] += gbin * (ly * hx) / count;
+                            g[y_high * W + x_high] += gbin * (ly * lx) / count;
+                        }
+                    }
+                }
+        }
+    }
+}
+
 /* torchvision.ops.roi_pool semantics (north_star extra, never called by the reference;
  * PARITY UNPINNED).  argmax: flat h*W+w index inside the channel plane, -1 when empty. */
 void orc_roi_pool(const float *feat, int B, int C, int H, int W, const float *rois, int K,

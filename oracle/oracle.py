@@ -309,6 +309,40 @@ def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, sel=None, 
     return out
 
 
+def roi_align_backward(grad_out, feat_shape, rois, output_size, spatial_scale, sampling_ratio, sel=None,
+                       sel_value=0, grad_feat=None):
+    """d(sum(out * grad_out)) / d feat of roi_align: (B,C,H,W), accumulated into grad_feat when given."""
+    grad_out = _f32(grad_out)
+    rois = _f32(rois).reshape(-1, 5)
+    B, C, H, W = feat_shape
+    K = rois.shape[0]
+    ph, pw = output_size
+    if grad_feat is None:
+        grad_feat = np.zeros((B, C, H, W), np.float32)
+    selp = sel.ctypes.data_as(_I32) if sel is not None else _null(_I32)
+    lib().orc_roi_align_backward(_fp(grad_out), ctypes.c_int(B), ctypes.c_int(C), ctypes.c_int(H), ctypes.c_int(W),
+                                 _fp(rois), ctypes.c_int(K), ctypes.c_int(ph), ctypes.c_int(pw),
+                                 ctypes.c_float(np.float32(spatial_scale)), ctypes.c_int(int(sampling_ratio)),
+                                 selp, ctypes.c_int(int(sel_value)), _fp(grad_feat))
+    return grad_feat
+
+
+def multiscale_roi_align_backward(grad_out, feature_shapes, list_proposals, image_shapes, output_size=(7, 7),
+                                  sampling_ratio=2):
+    """Backward of multiscale_roi_align with respect to every feature map -> list of (B,C,h,w)."""
+    rois = np.concatenate(
+        [np.concatenate([np.full((len(p), 1), i, np.float32), _f32(p).reshape(-1, 4)], 1)
+         for i, p in enumerate(list_proposals)], 0)
+    max_h = max(s[0] for s in image_shapes)
+    max_w = max(s[1] for s in image_shapes)
+    scales = [infer_scale(fs[-2:], (max_h, max_w)) for fs in feature_shapes]
+    if len(feature_shapes) == 1:
+        return [roi_align_backward(grad_out, feature_shapes[0], rois, output_size, scales[0], sampling_ratio)]
+    lvl = level_map(rois[:, 1:5], int(-math.log2(scales[0])), int(-math.log2(scales[-1])))
+    return [roi_align_backward(grad_out, fs, rois, output_size, s, sampling_ratio, sel=lvl, sel_value=l)
+            for l, (fs, s) in enumerate(zip(feature_shapes, scales))]
+
+
 def roi_pool(feat, rois, output_size, spatial_scale):
     feat = _f32(feat)
     rois = _f32(rois).reshape(-1, 5)

@@ -1340,3 +1340,78 @@ def test_closed_form_roi_pool(dev):
     out, arg = ops.roi_pool(T(g["rp.feat"], dev), T(g["rp.rois"], dev), (7, 7), float(g["rp.scale"]))
     assert np.array_equal(arg.cpu().numpy(), g["rp.argmax"])
     assert_bits_equal(out.cpu().numpy(), g["rp.expect"])
+
+
+# ---- RoIAlign backward (ROIHead/roi_head.py:127-130 under autograd: the RoI losses train the backbone) -----------
+@pytest.mark.parametrize("case", ["headline_map", "tail_channels_small_batch", "pyramid_with_oversize_plane"])
+def test_roi_align_backward_vs_oracle(dev, oracle, case):
+    """d(sum(out * G)) / d(features) through MultiScaleRoIAlign: the HIP backward (LDS-atomic plane kernel, the
+    RoI-split form for small batches, the global-atomic fallback for planes beyond LDS) against the oracle's
+    restatement of torchvision's roi_align_backward.  Sums are accumulated in a different order: 1e-5 relative
+    to the plane's scale."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    if case == "headline_map":
+        B, C, img, fsz, n = 3, 20, (600, 1000), [(37, 62)], [300, 1, 120]
+    elif case == "tail_channels_small_batch":
+        B, C, img, fsz, n = 1, 7, (256, 320), [(32, 40)], [64]
+    else:
+        B, C, img, fsz, n = 2, 3, (800, 1344), [(200, 336), (100, 168), (50, 84), (25, 42)], [150, 90]
+    names = [str(i) for i in range(len(fsz))]
+    feats = [torch.randn(B, C, h, w, device=dev, requires_grad=True) for h, w in fsz]
+    boxes = [realistic_boxes(rng, k, img[1], img[0]) for k in n]
+    boxes[0][0] = [-50.0, -40.0, 90.0, 70.0]             # starts outside the map
+    boxes[0][-1] = [img[1] - 30.0, img[0] - 20.0, img[1] + 60.0, img[0] + 80.0]   # runs off it
+    pool = ops.MultiScaleRoIAlign(names, (7, 7), 2)
+    out = pool(dict(zip(names, feats)), [T(b, dev) for b in boxes], [img])
+    assert out.requires_grad and out.shape == (sum(n), C, 7, 7)
+    G = torch.randn(out.shape, device=dev)
+    out.backward(G)
+    ref = oracle.multiscale_roi_align_backward(G.cpu().numpy(), [tuple(f.shape) for f in feats], boxes, [img])
+    for f, r in zip(feats, ref):
+        assert f.grad is not None and f.grad.shape == f.shape
+        np.testing.assert_allclose(f.grad.cpu().numpy(), r, rtol=RTOL, atol=1e-5 * max(1.0, float(np.abs(r).max())))
+    assert sum(float(np.abs(r).sum()) > 0 for r in ref) >= min(2, len(ref))
+
+
+def test_roi_align_backward_adjoint_of_closed_form(dev):
+    """<RoIAlign(f), G> = <f, RoIAlign^T(G)> with the affine planes of closed_form.npz, whose forward values are known
+    by arithmetic: pins the HIP backward without the oracle."""
+    from objectdetection_amd import ops
+    g = load_golden("closed_form.npz")
+    rng = np.random.default_rng(5)
+    feats = {n: T(g[f"ra4.feat{l}"], dev).requires_grad_(True) for l, n in enumerate("abcd")}
+    out = ops.MultiScaleRoIAlign(list("abcd"), (7, 7), 2)(feats, [T(g["ra4.boxes0"], dev), T(g["ra4.boxes1"], dev)],
+                                                          [tuple(int(v) for v in g["ra4.image_hw"])])
+    G = rng.standard_normal(g["ra4.expect"].shape).astype(np.float32)
+    out.backward(T(G, dev))
+    lvl = np.concatenate([g["ra4.levels0"], g["ra4.levels1"]])
+    for l, n in enumerate("abcd"):
+        lhs = (g["ra4.expect"].astype(np.float64) * G)[lvl == l].sum(axis=(0, 2, 3))
+        rhs = (g[f"ra4.feat{l}"].astype(np.float64) * feats[n].grad.cpu().numpy()).sum(axis=(0, 2, 3))
+        np.testing.assert_allclose(rhs, lhs, rtol=1e-5, atol=1e-3)
+
+
+def test_roi_head_training_sends_gradients_to_the_feature_maps(dev):
+    """ROIHead(force_eval=False).train(): the RoI losses reach the feature maps through the pooling, as they do in the
+    reference (torchvision's op is differentiable); under no_grad / for maps that need none, nothing is recorded."""
+    from objectdetection_amd.ROIHead import ROIHead, ROIPooling, TwoMLPHead, FasterRCNNPredictor
+    rng = np.random.default_rng(3)
+    info = (2, 256, 256)
+    feats = [torch.rand(2, 3, 128, 128, device=dev, requires_grad=True), torch.rand(2, 3, 64, 64, device=dev)]
+    props = [T(realistic_boxes(rng, 64, 256, 256), dev), T(realistic_boxes(rng, 35, 256, 256), dev)]
+    targets = [{'class': [1.0, 2.0], 'box': [[104, 78, 175, 183], [33, 88, 197, 123]]},
+               {'class': [2.0], 'box': [[104, 78, 205, 183]]}]
+    torch.manual_seed(1)
+    head = ROIHead(dict(pos_threshold=0.3, neg_threshold=0.3, num_sample=512, pos_fraction=0.25,
+                        regression_weights=[10., 10., 5., 5.], score_thresh=0.05, proposal_min_size=1e-3,
+                        nms_threshold=0.5, num_post_nms=1000, roi_pooling=ROIPooling(['1', '2'], [7, 7], 2),
+                        mlp_head=TwoMLPHead(3 * 49, 64).to(dev), predictor=FasterRCNNPredictor(64, 3).to(dev),
+                        force_eval=False)).train()
+    _, loss = head(props, feats, info, targets, [(250, 226), (256, 240)])
+    (loss["cls_loss"] + loss["reg_loss"]).backward()
+    assert feats[0].grad is not None and float(feats[0].grad.abs().sum()) > 0
+    assert feats[1].grad is None
+    with torch.no_grad():
+        out = head.roi_pooling({'1': feats[0], '2': feats[1]}, props, [(256, 256)])
+    assert not out.requires_grad

@@ -243,3 +243,42 @@ def test_closed_form_roi_pool(oracle):
     out, arg = oracle.roi_pool(g["rp.feat"], g["rp.rois"], (7, 7), float(g["rp.scale"]))
     assert np.array_equal(arg, g["rp.argmax"])
     assert_bits_equal(out, g["rp.expect"])
+
+
+def _rois_of(boxes):
+    return np.concatenate([np.concatenate([np.full((len(b), 1), i, np.float32), b], 1) for i, b in enumerate(boxes)])
+
+
+def test_roi_align_backward_is_the_adjoint_of_the_closed_form_forward(oracle):
+    """<RoIAlign(f), G> = <f, RoIAlign^T(G)>.  With f the affine planes of closed_form.npz the left side is known in
+    closed form (ra1.expect), so this pins the oracle's backward without going through the oracle's forward."""
+    g = load_golden("closed_form.npz")
+    rng = np.random.default_rng(5)
+    G = rng.standard_normal(g["ra1.expect"].shape).astype(np.float32)
+    feat = g["ra1.feat"]
+    grad = oracle.roi_align_backward(G, feat.shape, _rois_of([g["ra1.boxes0"], g["ra1.boxes1"]]), (7, 7), 1.0 / 16, 2)
+    lhs = (g["ra1.expect"].astype(np.float64) * G).sum(axis=(0, 2, 3))          # per channel
+    rhs = (feat.astype(np.float64) * grad).sum(axis=(0, 2, 3))
+    np.testing.assert_allclose(rhs, lhs, rtol=1e-5, atol=1e-3)
+    # four levels: each level's gradient only from the RoIs mapped to it
+    props = [g["ra4.boxes0"], g["ra4.boxes1"]]
+    feats = [g[f"ra4.feat{l}"] for l in range(4)]
+    G = rng.standard_normal(g["ra4.expect"].shape).astype(np.float32)
+    grads = oracle.multiscale_roi_align_backward(G, [f.shape for f in feats], props, [tuple(g["ra4.image_hw"])])
+    lvl = np.concatenate([g["ra4.levels0"], g["ra4.levels1"]])
+    for l in range(4):
+        lhs = (g["ra4.expect"].astype(np.float64) * G)[lvl == l].sum(axis=(0, 2, 3))
+        rhs = (feats[l].astype(np.float64) * grads[l]).sum(axis=(0, 2, 3))
+        np.testing.assert_allclose(rhs, lhs, rtol=1e-5, atol=1e-3)
+
+
+def test_roi_align_backward_adjoint_random(oracle):
+    rng = np.random.default_rng(6)
+    feat = rng.standard_normal((2, 5, 19, 23)).astype(np.float32)
+    boxes = [np.array([[10, 12, 200, 150], [-30, -20, 90, 400], [300, 100, 380, 140], [5, 5, 6, 6]], np.float32),
+             np.array([[0, 0, 368, 304], [100, 250, 500, 330]], np.float32)]
+    rois = _rois_of(boxes)
+    out = oracle.roi_align(feat, rois, (7, 7), 1.0 / 16, 2)
+    G = rng.standard_normal(out.shape).astype(np.float32)
+    grad = oracle.roi_align_backward(G, feat.shape, rois, (7, 7), 1.0 / 16, 2)
+    np.testing.assert_allclose((feat.astype(np.float64) * grad).sum(), (out.astype(np.float64) * G).sum(), rtol=1e-5)

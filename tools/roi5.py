@@ -1,0 +1,36 @@
+"""Config-5 MultiScaleRoIAlign alone (16 x 2,000 RoIs, C = 256, levels 100x168 .. 13x21):
+proposals are computed once, then the four level launches run `reps` times.  For rocprofv3 and A/B builds.
+    python tools/roi5.py [reps] [B]        (FRCNN_EXP_LIB=path: an experimental build of the library)"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import objectdetection_amd._lib as _l
+if os.environ.get("FRCNN_EXP_LIB"):
+    _l.LIB_PATH = os.path.abspath(os.environ["FRCNN_EXP_LIB"])
+import bench
+from objectdetection_amd import ops
+from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+dev = torch.device("cuda:0")
+x = bench.config5_inputs(B, dev)
+tv, ti = ops.topk_desc_nchw(x["cls"], 30000)
+boxes, _, _, count = ops.decode_clip_filter_nchw(x["anchors"], x["reg"], ti, tv, x["Himg"], x["Wimg"], 1e-3)
+keep, nk = ops.nms_sorted(boxes, count, 0.7, 2000)
+props = ops.gather_boxes(boxes, keep, nk)
+pool = ROIPooling(['1', '2', '3', '4'], [7, 7], 2)
+fd = {str(i + 1): f for i, f in enumerate(x["feats"][::-1])}
+fn = lambda: pool.forward_padded(fd, props, nk, [(x["Himg"], x["Wimg"])])
+for _ in range(3):
+    out, total = fn()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    out, total = fn()
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+nb = int(total) * x["C"] * 49 * 4
+print("config5 roi_align: %.4f ms per batch, %d RoIs, %.1f GB/s written, hbm_frac %.3f, checksum %.6e"
+      % (ms, int(total), nb / ms / 1e6, nb / ms / 1e6 / 8000, float(out[:int(total)].double().sum())))
