@@ -231,6 +231,15 @@ int frcnn_roi_pool_f32(const float *feat, int B, int C, int H, int W, const floa
                        int pooled_h, int pooled_w, float spatial_scale, float *out, int32_t *argmax,
                        void *stream);
 
+/* The same max pooling over zero-padded proposals, batched like frcnn_roi_align_batched_f32 (props: (B,P,4);
+ * count: (B) or NULL; output rows compacted in image order; total_out: (1) int32 or NULL): the form that runs
+ * at the headline shape (16 x 2,000 RoIs, C = 512) with the planes resident in LDS.  7 x 7 bins and a plane
+ * that fits LDS four channels at a time only (FRCNN_EINVAL otherwise: use frcnn_roi_pool_f32).  Not called by
+ * the reference (north_star: "RoI pooling to 7x7 ... argmax"); semantics are torchvision roi_pool's. */
+int frcnn_roi_pool_batched_f32(const float *feat, int B, int C, int H, int W, const float *props,
+                               const int32_t *count, int P, int pooled_h, int pooled_w, float spatial_scale,
+                               float *out, int32_t *argmax, int32_t *total_out, void *stream);
+
 /* ---- ROIHead eval post-process ---------------------------------------------
  * ROIHead/roi_head.py:178-209 for a whole batch in one launch.  props: (N,4) the images' proposal
  * lists concatenated; regs: (N,K,4); scores: (N,K) (softmax output); row_off: (B+1) int32 device,

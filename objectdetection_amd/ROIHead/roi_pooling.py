@@ -37,5 +37,12 @@ class ROIPooling(Module):
         return out
 
     def forward_padded(self, dict_feature_maps, props, count, image_size):
-        """Sync-free batched form: props (B,P,4) zero-padded, count (B) int32 on device."""
-        return self.roi_pooling.forward_padded(dict_feature_maps, props, count, image_size)
+        """Sync-free batched form: props (B,P,4) zero-padded, count (B) int32 on device.
+        -> (features (B*P,C,oh,ow) with the first sum(count) rows valid, total (1) int32 on device)."""
+        if self.mode == "align":
+            return self.roi_pooling.forward_padded(dict_feature_maps, props, count, image_size)
+        feats, scales, _, _ = self.roi_pooling._levels(dict_feature_maps, image_size)
+        if len(feats) != 1:
+            raise ValueError("max RoIPool mode is single-level")
+        out, self.last_argmax, total = ops.roi_pool_batched(feats[0], props, count, tuple(self.output_size), scales[0])
+        return out, total

@@ -50,6 +50,7 @@ SIGNATURES = {
     "frcnn_roi_align_batched_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _I, _P, _P, _P]),
     "frcnn_roi_align_batched_backward_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _I, _P, _P]),
     "frcnn_roi_pool_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "frcnn_roi_pool_batched_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
     "frcnn_roi_detect_filter_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P]),
     "frcnn_rpn_sampled_loss_f32": (_I, [_P, _P, _P, _P, _P, _I, _L, _F, _P, _P, _P, _P]),
     "frcnn_roi_loss_f32": (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),

@@ -339,6 +339,42 @@ __device__ __forceinline__ void rap_item(const float4 *s_plane, int WS, int row_
     }
 }
 
+// Staging of a chunk's planes (shared by the RoIAlign and max-RoIPool plane kernels): 4 coalesced plane reads ->
+// one 16-byte LDS write per pixel/group.  Four pixels per thread are fetched before any is written, so a
+// workgroup pays about three memory round trips for its 150 KB instead of nine.
+__device__ __forceinline__ void rap_stage_planes(float4 *s_plane, const float *__restrict__ fb, int G, int nc, int HW,
+                                                 int W, int WS)
+{
+    for (int t0 = threadIdx.x; t0 < G * HW; t0 += 4 * RAP_THREADS) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * RAP_THREADS;
+            v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (t < G * HW) {
+                const int g = t / HW;
+                const int p = t - g * HW;
+                const float *f = fb + (long long)(4 * g) * HW + p;
+                v[u].x = f[0];
+                if (4 * g + 1 < nc) v[u].y = f[HW];
+                if (4 * g + 2 < nc) v[u].z = f[2 * HW];
+                if (4 * g + 3 < nc) v[u].w = f[3 * HW];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * RAP_THREADS;
+            if (t < G * HW) {
+                const int g = t / HW;
+                const int p = t - g * HW;
+                const int y = p / W;
+                const int x = p - y * W;
+                s_plane[(y * G + g) * WS + (x ^ rap_swz(y))] = v[u];
+            }
+        }
+    }
+}
+
 // What bounds this kernel (A/B builds on MI355X, batch 16 x 2000 RoIs, C = 512; DESIGN.md has the
 // table): the OUTPUT STORE STREAM.  With the arithmetic removed the stores alone take 0.77 ms of
 // the 0.91 ms; the arithmetic alone (LDS taps + packed FMAs + per-item set-up) takes 0.66 ms and
@@ -398,38 +434,7 @@ roi_align_plane_kernel(const float *__restrict__ feat, int C, int H, int W,
         }
         if (!__syncthreads_or(mine)) return;
     }
-    // stage the chunk's planes: 4 coalesced plane reads -> one 16-byte LDS write per pixel/group.
-    // Four pixels per thread are fetched before any is written, so a workgroup pays about three
-    // memory round trips for its 150 KB instead of nine.
-    const float *fb = feat + ((long long)b * C + c0) * HW;
-    for (int t0 = threadIdx.x; t0 < G * HW; t0 += 4 * RAP_THREADS) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u * RAP_THREADS;
-            v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (t < G * HW) {
-                const int g = t / HW;
-                const int p = t - g * HW;
-                const float *f = fb + (long long)(4 * g) * HW + p;
-                v[u].x = f[0];
-                if (4 * g + 1 < nc) v[u].y = f[HW];
-                if (4 * g + 2 < nc) v[u].z = f[2 * HW];
-                if (4 * g + 3 < nc) v[u].w = f[3 * HW];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u * RAP_THREADS;
-            if (t < G * HW) {
-                const int g = t / HW;
-                const int p = t - g * HW;
-                const int y = p / W;
-                const int x = p - y * W;
-                s_plane[(y * G + g) * WS + (x ^ rap_swz(y))] = v[u];
-            }
-        }
-    }
+    rap_stage_planes(s_plane, feat + ((long long)b * C + c0) * HW, G, nc, HW, W, WS);
     __syncthreads();
     const int cnt = s_cnt;
     const int per = (cnt + splits - 1) / splits;
@@ -1017,5 +1022,172 @@ extern "C" int frcnn_roi_pool_f32(const float *feat, int B, int C, int H, int W,
     hipLaunchKernelGGL(roi_pool_kernel, dim3(K, chunks), dim3(256), 0, (hipStream_t)stream, feat, B,
                        C, H, W, rois, pooled_h, pooled_w, spatial_scale, out, argmax);
     FRCNN_CHECK_LAUNCH("roi_pool");
+    return FRCNN_OK;
+}
+
+// ---- max RoIPool over padded proposals, on the plane scheme ------------------------------------------
+// The batched form (K7 at the headline shape: 16 x 2,000 RoIs, C = 512).  Same organisation as
+// roi_align_plane_kernel: a workgroup owns (image, 16-channel chunk, RoI split), keeps the chunk's planes in
+// LDS as 4-channel pixels, and a wave takes one whole RoI per iteration with lane = bin, so that every
+// channel's 49 values -- and its 49 argmax indices -- leave as one 196-byte run each.  A bin's window is
+// scanned in row-major order with a strict `>`, which is torchvision's first-maximum rule; one LDS read
+// serves four channels.  Output rows are compacted in image order like RoIAlign's.
+struct PoolRec { // integer geometry of a RoI: round(coord * scale), extents max(end - start + 1, 1)
+    int rsw, rsh, rw, rh;
+};
+
+template <int GT, int WST>
+__global__ void __launch_bounds__(RAP_THREADS)
+roi_pool_plane_kernel(const float *__restrict__ feat, int C, int H, int W, const float4 *__restrict__ props,
+                      const int32_t *__restrict__ count, int P, int CC, float scale, int chunks, int splits, int B,
+                      float *__restrict__ out, int32_t *__restrict__ argmax, int32_t *__restrict__ total_out)
+{
+    extern __shared__ float4 s_plane[];
+    __shared__ int4 s_rec[RAP_SEG];
+    __shared__ int s_off, s_cnt;
+    const int slot = blockIdx.x >> 3; // block order as in roi_align_plane_kernel
+    const int chunk = slot % chunks;
+    const int grp = (slot / chunks) * 8 + (blockIdx.x & 7);
+    if (grp >= splits * B) return;
+    const int split = grp % splits;
+    const int b = grp / splits;
+    const int c0 = chunk * CC;
+    const int nc = min(CC, C - c0);
+    const int G = GT ? GT : (nc + 3) >> 2;
+    const int HW = H * W;
+    const int WS = WST ? WST : (W + 15) & ~15;
+    if (threadIdx.x == 0) {
+        int off = 0, tot = 0;
+        for (int i = 0; i < B; ++i) {
+            int c = count ? count[i] : P;
+            c = c < 0 ? 0 : (c > P ? P : c);
+            if (i < b) off += c;
+            if (i == b) s_cnt = c;
+            tot += c;
+        }
+        s_off = off;
+        if (total_out && chunk == 0 && grp == 0) *total_out = tot;
+    }
+    rap_stage_planes(s_plane, feat + ((long long)b * C + c0) * HW, G, nc, HW, W, WS);
+    __syncthreads();
+    const int cnt = s_cnt;
+    const int per = (cnt + splits - 1) / splits;
+    const int j0 = split * per;
+    const int j1 = min(cnt, j0 + per);
+    const int row_stride = G * WS;
+    const float4 *pb = props + (long long)b * P;
+    const long long o0 = ((long long)s_off * C + c0) * 49;
+    const int bin = threadIdx.x & 63;
+    const int ph = bin / 7, pw = bin - ph * 7;
+    for (int seg = j0; seg < j1; seg += RAP_SEG) {
+        const int nseg = min(RAP_SEG, j1 - seg);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nseg; i += RAP_THREADS) {
+            const float4 box = pb[seg + i];
+            int4 r;
+            r.x = (int)roundf(box.x * scale);
+            r.y = (int)roundf(box.y * scale);
+            r.z = max((int)roundf(box.z * scale) - r.x + 1, 1);
+            r.w = max((int)roundf(box.w * scale) - r.y + 1, 1);
+            s_rec[i] = r;
+        }
+        __syncthreads();
+        for (int jl = (int)(threadIdx.x >> 6); jl < (bin < 49 ? nseg : 0); jl += RAP_THREADS / 64) {
+            const int4 r = s_rec[jl];
+            const float bin_h = (float)r.w / 7.0f, bin_w = (float)r.z / 7.0f;
+            int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
+            int ws = (int)floorf((float)pw * bin_w), we = (int)ceilf((float)(pw + 1) * bin_w);
+            hs = min(max(hs + r.y, 0), H);
+            he = min(max(he + r.y, 0), H);
+            ws = min(max(ws + r.x, 0), W);
+            we = min(max(we + r.x, 0), W);
+            const bool empty = (he <= hs) || (we <= ws);
+            const long long o = o0 + (long long)(seg + jl) * C * 49 + bin;
+            // all channel groups of the chunk per window cell: 16 running maxima and their indices
+            float mx[4 * (GT ? GT : 4)];
+            int mi[4 * (GT ? GT : 4)];
+#pragma unroll
+            for (int q = 0; q < 4 * (GT ? GT : 4); ++q) {
+                mx[q] = empty ? 0.0f : -3.402823466e+38f;
+                mi[q] = -1;
+            }
+            int h = hs, w = ws;
+            for (int left = empty ? 0 : (he - hs) * (we - ws); left > 0; --left) {
+                const float4 *cell = s_plane + __mul24(h, row_stride) + (w ^ rap_swz(h));
+                const int idx = h * W + w;
+#pragma unroll
+                for (int g = 0; g < (GT ? GT : 4); ++g) {
+                    if (GT || g < G) {
+                        const float4 v = cell[g * WS];
+                        if (v.x > mx[4 * g]) { mx[4 * g] = v.x; mi[4 * g] = idx; }
+                        if (v.y > mx[4 * g + 1]) { mx[4 * g + 1] = v.y; mi[4 * g + 1] = idx; }
+                        if (v.z > mx[4 * g + 2]) { mx[4 * g + 2] = v.z; mi[4 * g + 2] = idx; }
+                        if (v.w > mx[4 * g + 3]) { mx[4 * g + 3] = v.w; mi[4 * g + 3] = idx; }
+                    }
+                }
+                if (++w == we) {
+                    w = ws;
+                    ++h;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4 * (GT ? GT : 4); ++q) {
+                if (GT || q < nc) {
+                    out[o + q * 49] = mx[q];
+                    argmax[o + q * 49] = mi[q];
+                }
+            }
+        }
+    }
+}
+
+extern "C" int frcnn_roi_pool_batched_f32(const float *feat, int B, int C, int H, int W, const float *props,
+                                          const int32_t *count, int P, int pooled_h, int pooled_w,
+                                          float spatial_scale, float *out, int32_t *argmax, int32_t *total_out,
+                                          void *stream)
+{
+    FRCNN_REQUIRE(B > 0 && B <= 65535 && C > 0 && H > 0 && W > 0 && P >= 0, "roi_pool_batched: bad shape");
+    FRCNN_REQUIRE(pooled_h == 7 && pooled_w == 7, "roi_pool_batched: only 7 x 7 bins (got %d x %d); use frcnn_roi_pool_f32",
+                  pooled_h, pooled_w);
+    if (P == 0) {
+        if (total_out) {
+            hipError_t e = hipMemsetAsync(total_out, 0, sizeof(int32_t), (hipStream_t)stream);
+            FRCNN_REQUIRE(e == hipSuccess, "roi_pool_batched: memset failed");
+        }
+        return FRCNN_OK;
+    }
+    FRCNN_REQUIRE(feat && props && out && argmax, "roi_pool_batched: null pointer");
+    int WS = (W + 15) & ~15;
+    if (W <= 64 && (long long)H * 64 * 4 * 16 <= RAP_LDS_BUDGET) WS = 64;
+    const long long plane_bytes = (long long)H * WS * 4;
+    FRCNN_REQUIRE(plane_bytes * 4 <= RAP_LDS_BUDGET && (long long)P * 49 < (1ll << 30) && (long long)H * WS * 4 < (1 << 23),
+                  "roi_pool_batched: a %d x %d plane does not fit LDS; use frcnn_roi_pool_f32", H, W);
+    int CC = 16;
+    while (CC > 4 && plane_bytes * CC > RAP_LDS_BUDGET) CC >>= 1;
+    if (CC > C) CC = (C + 3) / 4 * 4;
+    const int chunks = (C + CC - 1) / CC;
+    int splits = (RAP_WG_TARGET + chunks * B - 1) / (chunks * B);
+    if (splits < 1) splits = 1;
+    if (splits > 16) splits = 16;
+    const size_t lds = (size_t)plane_bytes * (size_t)CC;
+    const bool full = (CC == 16) && (C % 16 == 0) && WS == 64;
+    {
+        static size_t granted4[FRCNN_MAX_DEVICES], granted0[FRCNN_MAX_DEVICES];
+        hipError_t e = full ? frcnn_reserve_dynamic_lds((const void *)roi_pool_plane_kernel<4, 64>, lds, granted4)
+                            : frcnn_reserve_dynamic_lds((const void *)roi_pool_plane_kernel<0, 0>, lds, granted0);
+        FRCNN_REQUIRE(e == hipSuccess, "roi_pool_batched: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    }
+    const long long groups8 = ((long long)splits * B + 7) / 8 * 8;
+    FRCNN_REQUIRE(groups8 * chunks < (1ll << 31), "roi_pool_batched: grid too large");
+    const dim3 grid((unsigned)(groups8 * chunks));
+    if (full)
+        hipLaunchKernelGGL((roi_pool_plane_kernel<4, 64>), grid, dim3(RAP_THREADS), lds, (hipStream_t)stream, feat, C, H,
+                           W, (const float4 *)props, count, P, CC, spatial_scale, chunks, splits, B, out, argmax,
+                           total_out);
+    else
+        hipLaunchKernelGGL((roi_pool_plane_kernel<0, 0>), grid, dim3(RAP_THREADS), lds, (hipStream_t)stream, feat, C, H,
+                           W, (const float4 *)props, count, P, CC, spatial_scale, chunks, splits, B, out, argmax,
+                           total_out);
+    FRCNN_CHECK_LAUNCH("roi_pool_plane");
     return FRCNN_OK;
 }

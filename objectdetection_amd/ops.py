@@ -631,6 +631,29 @@ def roi_pool(feat, rois, output_size, spatial_scale):
     return out, arg
 
 
+def roi_pool_batched(feat, props, count, output_size, spatial_scale):
+    """torchvision roi_pool (max) over zero-padded proposals (B,P,4) with per-image counts (B) int32 or None.
+    -> (out (B*P,C,7,7), argmax (B*P,C,7,7) int32, total (1) int32); the first sum(count) rows are valid, in image
+    order.  Planes stay resident in LDS (7 x 7 bins, maps up to about 37 x 64 at 16 channels a time)."""
+    _need_gpu(feat, props, count)
+    feat, props = _f32c(feat), _f32c(props)
+    B, C, H, W = feat.shape
+    if props.dim() != 3 or props.shape[0] != B or props.shape[2] != 4:
+        raise ValueError("roi_pool_batched expects props (B,P,4); got %s for B = %d" % (tuple(props.shape), B))
+    P = props.shape[1]
+    if count is not None and count.dtype != torch.int32:
+        count = count.to(torch.int32)
+    ph, pw = int(output_size[0]), int(output_size[1])
+    out = torch.empty((B * P, C, ph, pw), dtype=torch.float32, device=feat.device)
+    arg = torch.empty((B * P, C, ph, pw), dtype=torch.int32, device=feat.device)
+    total = torch.empty((1,), dtype=torch.int32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        rc = _lib.load().frcnn_roi_pool_batched_f32(_ptr(feat), B, C, H, W, _ptr(props), _ptr(count), P, ph, pw,
+                                                    float(spatial_scale), _ptr(out), _ptr(arg), _ptr(total), _stream())
+    _lib.check(rc, "roi_pool_batched")
+    return out, arg, total
+
+
 def infer_scale(feature_hw, image_hw):
     """torchvision poolers._infer_scale: 2 ** round(log2(fp32(feat/img))); both axes must agree."""
     scales = []

@@ -795,6 +795,73 @@ def test_roi_pool_max_vs_oracle(dev, oracle):
     assert (ref_arg == -1).any()
 
 
+@pytest.mark.parametrize("B,C,H,W,counts", [(2, 19, 37, 62, [150, 37]), (3, 32, 37, 62, [0, 600, 1]),
+                                             (1, 5, 20, 30, [64]), (2, 16, 50, 84, [40, 40])])
+def test_roi_pool_batched_vs_oracle(dev, oracle, B, C, H, W, counts):
+    """The plane-scheme max RoIPool over padded proposals (K7 at batch shapes): values and argmax bit-exact against
+    the oracle's roi_pool on the concatenated roi list; ragged counts, tail channels, a wider map (generic
+    instantiation), RoIs running off the map (empty bins -> 0 / -1)."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(C * 7 + H)
+    scale = 1 / 16
+    feat = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    feat[0, 0, :3, :5] = 1.25      # a flat patch: the first maximum must win
+    P = max(counts)
+    props = np.zeros((B, P, 4), np.float32)
+    rows = []
+    for b, n in enumerate(counts):
+        bx = realistic_boxes(rng, n, W * 16.0, H * 16.0)
+        if n > 2:
+            bx[0] = [W * 16 - 20, H * 16 - 20, W * 16 + 400, H * 16 + 300]   # mostly outside
+            bx[1] = [0, 0, 70, 40]                                            # over the flat patch
+            bx[2] = [40.5, 24.5, 136.5, 120.5]                                # halves: round away from zero
+        props[b, :n] = bx
+        rows.append(np.concatenate([np.full((n, 1), b, np.float32), bx], 1))
+    rois = np.concatenate(rows)
+    ref, ref_arg = oracle.roi_pool(feat, rois, (7, 7), scale)
+    out, arg, total = ops.roi_pool_batched(T(feat, dev), T(props, dev), T(counts, dev, torch.int32), (7, 7), scale)
+    n = sum(counts)
+    assert int(total) == n
+    assert np.array_equal(arg[:n].cpu().numpy(), ref_arg)
+    assert_bits_equal(out[:n].cpu().numpy(), ref)
+
+
+def test_roi_pool_batched_full_size_and_module(dev, oracle):
+    """BASELINE config 2 shape (16 x 2,000 RoIs, C = 512) through ROIPooling(mode='max').forward_padded: a sample of
+    rows against the oracle, bit-exact; argmax always points at the value it reports."""
+    from objectdetection_amd.ROIHead import ROIPooling
+    rng = np.random.default_rng(2)
+    B, C, H, W, P = 16, 512, 37, 62, 2000
+    feat = torch.randn((B, C, H, W), generator=torch.Generator().manual_seed(3)).to(dev)
+    props = np.stack([realistic_boxes(rng, P) for _ in range(B)])
+    counts = np.full(B, P, np.int32)
+    counts[3] = 1234
+    pool = ROIPooling(['1'], [7, 7], 2, mode="max")
+    out, total = pool.forward_padded({'1': feat}, T(props, dev), T(counts, dev, torch.int32), [(600, 1000)])
+    n = int(counts.sum())
+    assert int(total) == n
+    arg = pool.last_argmax
+    row0 = np.concatenate([[0], np.cumsum(counts)])
+    sel = rng.choice(n, 40, replace=False)
+    img = np.searchsorted(row0, sel, side="right") - 1
+    rois = np.stack([np.concatenate([[b], props[b, r - row0[b]]]) for b, r in zip(img, sel)]).astype(np.float32)
+    chans = rng.choice(C, 24, replace=False)
+    ref, ref_arg = oracle.roi_pool(feat[:, chans].cpu().numpy(), rois, (7, 7), 1 / 16)
+    got = out[torch.as_tensor(sel, device=dev)][:, torch.as_tensor(chans, device=dev)]
+    got_arg = arg[torch.as_tensor(sel, device=dev)][:, torch.as_tensor(chans, device=dev)]
+    assert np.array_equal(got_arg.cpu().numpy(), ref_arg)
+    assert_bits_equal(got.cpu().numpy(), ref)
+    # size-independent property on everything: the value IS the feature at argmax (or 0 / -1 for an empty bin)
+    o, a = out[:n], arg[:n]
+    bidx = torch.repeat_interleave(torch.arange(B, device=dev), torch.as_tensor(counts, device=dev).long())
+    for c in (0, 77, 511):
+        plane = feat[bidx, c].reshape(n, -1)
+        ac = a[:, c].reshape(n, 49).long()
+        picked = torch.gather(plane, 1, ac.clamp(min=0))
+        want = torch.where(ac >= 0, picked, torch.zeros_like(picked))
+        assert torch.equal(o[:, c].reshape(n, 49), want)
+
+
 # ------------------------------------------------------------------------------ end to end
 def synth_head_outputs(rng, B, fsz, na=9):
     list_cls, list_regs = [], []
@@ -888,7 +955,7 @@ def test_rpn_training_targets_and_sampling(dev, oracle):
         assert int((l == 1).sum()) > 0
 
 
-class _FixedHead(torch.nn.Module):
+class _RecordedHead(torch.nn.Module):
     """Stands in for the (out of scope) conv head: returns the recorded outputs, on the autograd graph."""
 
     def __init__(self, cls, regs):
@@ -910,7 +977,7 @@ def test_rpn_training_half_sampling_golden(dev):
     info = tuple(int(v) for v in g["rpn.info"])
     fsz = [tuple(int(v) for v in hw) for hw in g["rpn.fsz"]]
     S, f, neg, pos = g["rpn.params"]
-    head = _FixedHead([T(g[f"rpn.cls{l}"], dev) for l in range(len(fsz))],
+    head = _RecordedHead([T(g[f"rpn.cls{l}"], dev) for l in range(len(fsz))],
                       [T(g[f"rpn.reg{l}"], dev) for l in range(len(fsz))])
     rpn = RPN(dict(anchor_generator=AnchorGenerator(), rpn_head=head, num_pre_nms=500, num_post_nms=100,
                    nms_threshold=0.7, proposal_min_size=1e-3, pos_threshold=float(pos), neg_threshold=float(neg),
@@ -1338,6 +1405,12 @@ def test_closed_form_roi_pool(dev):
     from objectdetection_amd import ops
     g = load_golden("closed_form.npz")
     out, arg = ops.roi_pool(T(g["rp.feat"], dev), T(g["rp.rois"], dev), (7, 7), float(g["rp.scale"]))
+    assert np.array_equal(arg.cpu().numpy(), g["rp.argmax"])
+    assert_bits_equal(out.cpu().numpy(), g["rp.expect"])
+    # and the batched plane-scheme kernel (one image, all RoIs)
+    out, arg, total = ops.roi_pool_batched(T(g["rp.feat"], dev), T(g["rp.rois"][None, :, 1:], dev), None, (7, 7),
+                                           float(g["rp.scale"]))
+    assert int(total) == g["rp.rois"].shape[0]
     assert np.array_equal(arg.cpu().numpy(), g["rp.argmax"])
     assert_bits_equal(out.cpu().numpy(), g["rp.expect"])
 
