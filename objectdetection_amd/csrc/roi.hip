@@ -836,6 +836,12 @@ roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, in
 #ifndef RAP_WG_TARGET
 #define RAP_WG_TARGET (4 * 256)
 #endif
+#ifndef RAP_WG_TARGET_ML
+#define RAP_WG_TARGET_ML 256 // config 5: P4 191 -> 167 us, P5 + P6 96 -> 62 us against 1024
+#endif
+#ifndef RAD_SPLITS_BEHIND
+#define RAD_SPLITS_BEHIND 16 // config 5: 128 -> 86 us against 128 splits (32: 88, 64: 101)
+#endif
 #define RAP_LDS_BUDGET (150 * 1024) // dynamic part (8 channels of a 50 x 96 plane); 8.7 KB of static LDS on top
 
 extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W,
@@ -873,7 +879,10 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         // RoI splits: about four workgroups per CU.  Fewer, longer workgroups stage fewer planes
         // (0.745 ms at 2 per CU, 0.748 at 4, 0.770 at 8, 0.838 at 16); shorter ones let the small
         // kernels of the next batch on another stream find a free CU sooner (bench.py pipelining).
-        int splits = (RAP_WG_TARGET + chunks * B - 1) / (chunks * B);
+        // (one level of several: only a share of the RoIs is pooled here, and every RoI split stages the planes
+        // again -- fewer, longer workgroups)
+        const int wg_target = n_levels > 1 ? RAP_WG_TARGET_ML : RAP_WG_TARGET;
+        int splits = (wg_target + chunks * B - 1) / (chunks * B);
         if (splits < 1) splits = 1;
         if (splits > 16) splits = 16;
         size_t lds = (size_t)plane_bytes * (size_t)CC;
@@ -948,7 +957,9 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
         }
     }
     int chunks = (C + RA_CHUNK - 1) / RA_CHUNK;
-    int splits = P < 128 ? P : 128;
+    // behind the window kernel only the few oversize RoIs are left: fewer workgroups, several RoIs each
+    const int want = nwy > 0 ? RAD_SPLITS_BEHIND : 128;
+    int splits = P < want ? P : want;
     hipLaunchKernelGGL(roi_align_batched_direct_kernel, dim3(splits, chunks, B), dim3(256), 0,
                        (hipStream_t)stream, feat, C, H, W, (const float4 *)props, count, P, pooled_h,
                        pooled_w, spatial_scale, sampling_ratio, level, n_levels, k_min, k_max, nwy, nwx, out,

@@ -21,3 +21,12 @@ for l in range(3, 7):
         l, int(m.sum()), 100.0 * m.float().mean(), span.median() if m.any() else 0, span.quantile(0.9) if m.any() else 0,
         span.max() if m.any() else 0, 100.0 * (span > 31).float().mean() if m.any() else 0,
         100.0 * (span > 47).float().mean() if m.any() else 0))
+# finer histogram of the P3 spans (cells), for choosing window sizes
+m = lvl == 3
+span = torch.maximum(w[m], h[m]) / 8
+for t in (9, 13, 17, 21, 25, 29, 33, 41, 49):
+    print("P3 span <= %2d cells: %5.1f %%" % (t, 100.0 * (span <= t).float().mean()))
+m = lvl == 4
+span = torch.maximum(w[m], h[m]) / 16
+for t in (17, 25, 33, 49):
+    print("P4 span <= %2d cells: %5.1f %%" % (t, 100.0 * (span <= t).float().mean()))
