@@ -319,8 +319,8 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
                path_hbm_frac=(roi_bytes + rest_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                roofline=dict(bound="hbm", kernel="roi_align_plane_kernel", achieved=roi_bytes / (ra_ms * 1e-3) / 1e9,
                              peak=HBM_PEAK_GBPS, unit="GB/s", frac=roi_bytes / (ra_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             traffic=traffic, traffic_source="pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE, "
-                             "separate passes; profiles/r01_step12_roi_align_pmc.csv)" if traffic else None,
+                             traffic=traffic, traffic_source=("pmc_traffic.json (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE, "
+                             "separate passes; " + str(pmc.get("source", "profiles/")) + ")") if traffic else None,
                              algorithmic_bytes_per_launch=roi_bytes, launch_ms=ra_ms,
                              dominant_stage=max(stage_ms, key=stage_ms.get)))
     return res, props, n_keep
@@ -471,6 +471,8 @@ def main():
         extras.update(targets_microbench(path, dev))
         extras.update(roi_pool_microbench(path, dev))
         extras.update(config5_microbench(dev))
+        c64 = config5_microbench(dev, B=64, reps=3)   # BASELINE configs[4] names batch 64
+        extras["config5_A200907_k30000_C256_batch64"] = c64["config5_A200907_k30000_C256"]
         extras.update(hbm_probe(dev))
 
     if rank == 0:
@@ -619,6 +621,23 @@ def next_rows_microbench(dev):
     ms = timed(post)
     res["roi_head_eval_postprocess"] = {"ms": ms, "candidates": B * Pn * Kc2,
                                         "algorithmic_bytes": B * Pn * Kc2 * 4 + B * Pn * 16}
+    # RoIAlign backward at the headline shape (16 x 2,000 RoIs, C = 512): what autograd runs through the pooling when
+    # the RoI losses train the backbone (roi_head.py:127-130).  Reads grad_out once, writes the gradient planes once.
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    feat = torch.randn((B, C, FH, FW), generator=g).to(dev).requires_grad_(True)
+    rng = np.random.default_rng(17)
+    cx, cy = rng.uniform(0, IMG_W, (B, Pn)), rng.uniform(0, IMG_H, (B, Pn))
+    bw, bh = 16 * 2 ** rng.uniform(0, 5, (B, Pn)), 16 * 2 ** rng.uniform(0, 5, (B, Pn))
+    props = torch.as_tensor(np.stack([(cx - bw / 2).clip(0, IMG_W), (cy - bh / 2).clip(0, IMG_H),
+                                      (cx + bw / 2).clip(0, IMG_W), (cy + bh / 2).clip(0, IMG_H)], 2).astype(np.float32)).to(dev)
+    cfg = ((7, 7), 2, (1.0 / 16,), 4, 4)
+    gout = torch.randn((B * Pn, C, 7, 7), generator=g, dtype=torch.float32).to(dev)
+    ms = timed(lambda: ops.roi_align_levels_backward(cfg, props, None, gout, [tuple(feat.shape)]), reps=5)
+    nbytes = B * Pn * C * 49 * 4 + B * C * FH * FW * 4
+    res["roi_align_backward_B16_K2000_C512"] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / ms / 1e6,
+                                                "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS,
+                                                "kernel": "roi_align_plane_backward_kernel (LDS float atomics)"}
+    del gout, feat
     # row 4: decode backward on the batch's 16 x 12,000 candidates
     n = B * PRE_NMS
     box = torch.rand(n, 4, generator=g).to(dev) * 500

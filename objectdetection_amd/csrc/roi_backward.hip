@@ -17,9 +17,18 @@
 #define RAB_THREADS 1024
 #define RAB_LDS_BUDGET (150 * 1024)
 
+#ifndef RAB_EXP
+#define RAB_EXP 0
+#endif
 __device__ __forceinline__ void lds_add(float *p, float v)
 {
+#if RAB_EXP == 1 // A/B: plain read-modify-write (wrong sums, speed probe only)
+    *p += v;
+#elif RAB_EXP == 2 // A/B: atomics, but every lane on its own address
+    __hip_atomic_fetch_add(p - (p - (float *)0) % 64 + (threadIdx.x & 63), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_f32, result unused
+#endif
 }
 
 // The four samples of bin (ph, pw) of a RoI record (start_w, start_h, bin_w, bin_h in feature pixels): the

@@ -133,6 +133,30 @@ def test_targets_batched_vs_oracle(dev, oracle):
     assert (out["label"] > 0).sum() > 0
 
 
+def test_proposal_targets_config3_shape_vs_oracle(dev, oracle):
+    """BASELINE configs[2], the ProposalTarget half at its own shape: per-image box_1 (B, 2,000 proposals, 4) against
+    100 boxes per image with class labels, thresholds 0.5 / 0.5, weights [10,10,5,5], batch 16 in one launch."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(33)
+    B, P, M = 16, 2000, 100
+    props = np.stack([realistic_boxes(rng, P) for _ in range(B)])
+    w = rng.uniform(16, 256, (B, M)); h = rng.uniform(16, 256, (B, M))
+    x1 = rng.uniform(0, 1000 - w); y1 = rng.uniform(0, 600 - h)
+    gt = np.stack([x1, y1, x1 + w, y1 + h], 2).astype(np.float32)
+    props[:, :M] = gt + rng.normal(0, 3, gt.shape).astype(np.float32)      # proposals near the boxes: positives exist
+    lab = rng.integers(1, 21, (B, M)).astype(np.float32)
+    out = ops.iou_label_encode(T(props, dev), T(gt, dev), None, 0.5, 0.5, T(lab, dev), [10.0, 10.0, 5.0, 5.0])
+    n_pos = 0
+    for i in range(B):
+        l, a, mx, dv = oracle.iou_label_encode(props[i], gt[i], 0.5, 0.5, lab[i], [10.0, 10.0, 5.0, 5.0])
+        assert_bits_equal(out["label"][i].cpu().numpy(), l)
+        assert np.array_equal(out["argmax"][i].cpu().numpy(), a)
+        assert_bits_equal(out["max_iou"][i].cpu().numpy(), mx)
+        np.testing.assert_allclose(out["dev"][i].cpu().numpy(), dv, rtol=RTOL, atol=1e-6)
+        n_pos += int((l > 0).sum())
+    assert n_pos > B * 50
+
+
 # ------------------------------------------------------------------- decode / clip / filter
 @pytest.mark.parametrize("K", [1, 3])
 def test_box_regression_golden(dev, K):
