@@ -200,34 +200,6 @@ extern "C" int frcnn_roi_align_f32(const float *feat, int B, int C, int H, int W
 // lane = bin, so each channel store is one 196-byte run and the 16 stores of an iteration fill a
 // contiguous 3136-byte piece of the (K, C, 7, 7) output.
 
-struct AxisSample { // one 1-D bilinear sample: taps lo/hi with weights (zero when out of range)
-    int lo, hi;
-    float wlo, whi;
-    bool ok;
-};
-
-__device__ __forceinline__ AxisSample axis_sample(float v, int n)
-{
-    AxisSample a;
-    bool ok = !(v < -1.0f || v > (float)n);
-    if (v <= 0.0f) v = 0.0f;
-    int lo = (int)v, hi;
-    if (lo >= n - 1) {
-        hi = lo = n - 1;
-        v = (float)lo;
-    } else {
-        hi = lo + 1;
-    }
-    float l = v - (float)lo;
-    float h = 1.0f - l;
-    a.lo = ok ? lo : 0;
-    a.hi = ok ? hi : 0;
-    a.wlo = ok ? h : 0.0f;
-    a.whi = ok ? l : 0.0f;
-    a.ok = ok;
-    return a;
-}
-
 #define RAP_THREADS 1024
 #define RAP_SEG 512 // RoIs whose geometry is staged in LDS at a time (10 KB)
 

@@ -56,3 +56,32 @@ __device__ __forceinline__ int map_level(float4 p, int k_min, int k_max)
     return (int)t - k_min;
 }
 
+
+struct AxisSample { // one 1-D bilinear sample: taps lo/hi with weights (zero when out of range)
+    int lo, hi;
+    float wlo, whi;
+    bool ok;
+};
+
+__device__ __forceinline__ AxisSample axis_sample(float v, int n)
+{
+    AxisSample a;
+    bool ok = !(v < -1.0f || v > (float)n);
+    if (v <= 0.0f) v = 0.0f;
+    int lo = (int)v, hi;
+    if (lo >= n - 1) {
+        hi = lo = n - 1;
+        v = (float)lo;
+    } else {
+        hi = lo + 1;
+    }
+    float l = v - (float)lo;
+    float h = 1.0f - l;
+    a.lo = ok ? lo : 0;
+    a.hi = ok ? hi : 0;
+    a.wlo = ok ? h : 0.0f;
+    a.whi = ok ? l : 0.0f;
+    a.ok = ok;
+    return a;
+}
+
