@@ -15,7 +15,10 @@
 #include "common.h"
 #include "roi_common.h"
 
-#define RAB_LDS_BUDGET (150 * 1024)
+#ifndef RAB_EXP
+#define RAB_EXP 0
+#endif
+#define RAB_LDS_BUDGET (160 * 1024 - 256) // dynamic LDS of the plane kernel: planes + tables
 
 __device__ __forceinline__ float4 rab_record(float4 box, float scale)
 {
@@ -26,49 +29,154 @@ __device__ __forceinline__ float4 rab_record(float4 box, float scale)
     return make_float4(start_w, start_h, roi_w / 7.0f, roi_h / 7.0f);
 }
 
-__device__ __forceinline__ float lane_get(float v, int src_lane) // src_lane the same for every lane
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4))); // a 16-byte load from a 4-byte-aligned address
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+
+// The cells that the 14 samples of an axis touch: samples grow with (bin, sample), so the first tap of the first
+// valid sample and the last tap of the last valid one bound them.  False when every sample is outside [-1, n].
+__device__ __forceinline__ bool axis_range(float start, float bin, int n, int &cmin, int &cmax)
 {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+    float vfirst = 0.0f, vlast = 0.0f;
+    bool any = false;
+#pragma unroll
+    for (int p = 0; p < 7; ++p)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float v = start + (float)p * bin + ((float)s + 0.5f) * bin / 2.0f; // the forward's expression
+            const bool ok = !(v < -1.0f || v > (float)n);
+            vfirst = (ok && !any) ? v : vfirst;
+            vlast = ok ? v : vlast;
+            any = any || ok;
+        }
+    cmin = axis_sample(vfirst, n).lo;
+    cmax = axis_sample(vlast, n).hi;
+    return any;
 }
 
-// Weight that the two samples of an axis record put on cell `cell` (0 when it is none of their taps).  A sample's
-// taps are lo and lo + 1 (a sample clamped to the last cell has all its weight on lo and 0 on "lo + 1", so the
-// out-of-range cell never receives anything); idx holds lo of the two samples, 0x7FFF0000-ish sentinels for an
-// invalid one.
-__device__ __forceinline__ float axis_weight(const int2 lo, const float4 w, int cell)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// grad_out of one RoI as the lanes of a wave hold it: rows q and q + 4 of the 7 x 7 block (q = lane / 16), both
+// channels; lanes q = 3 have no second row and load the first one again (never used: their T is forced to zero).
+struct RabG {
+    f32x4u a0, b0, a2, b2;
+    f32x3u a1, b1, a3, b3;
+};
+
+__device__ __forceinline__ void rab_load(RabG &g, const float *__restrict__ gb, int j, int C, int q, int ch1_off)
 {
-    const int d0 = cell - lo.x, d1 = cell - lo.y;
-    return (d0 == 0 ? w.x : (d0 == 1 ? w.y : 0.0f)) + (d1 == 0 ? w.z : (d1 == 1 ? w.w : 0.0f));
+    const float *gp = gb + (long long)j * C * 49 + q * 7;
+    const float *gq = gp + ch1_off; // (a missing second channel computes on the first one's data into the unused half of the cells)
+    const int o2 = q < 3 ? 28 : 0;
+#if RAB_EXP == 1 // speed probe: no grad_out loads
+    const float fz = (float)(j + o2) + (gp == gq ? 1.0f : 0.0f);
+    g.a0 = g.b0 = g.a2 = g.b2 = (f32x4u){fz, fz, fz, fz};
+    g.a1 = g.b1 = g.a3 = g.b3 = (f32x3u){fz, fz, fz};
+#else
+    g.a0 = *(const f32x4u *)gp;
+    g.b0 = *(const f32x4u *)gq;
+    g.a1 = *(const f32x3u *)(gp + 4);
+    g.b1 = *(const f32x3u *)(gq + 4);
+    g.a2 = *(const f32x4u *)(gp + o2);
+    g.b2 = *(const f32x4u *)(gq + o2);
+    g.a3 = *(const f32x3u *)(gp + o2 + 4);
+    g.b3 = *(const f32x3u *)(gq + o2 + 4);
+#endif
 }
 
-// Workgroup = (image, chunk of nw channels, RoI split), nw waves: WAVE w OWNS CHANNEL c0 + w and its gradient
-// plane in LDS, so no two waves ever add into the same plane, and inside a wave the lanes are the CELLS of a row
-// segment -- distinct addresses -- so the scatter needs no atomics at all: ds_read, add, ds_write.  (LDS float
-// atomics are what the first version used: ds_add_f32 costs ~130 cycles per wave instruction on gfx950 whether or
-// not lanes collide -- 68 ms at the headline shape, 62 ms with every lane on its own address, 4.6 ms with plain
-// read-modify-write.)  RoIAlign's weights are separable, grad_feat[y][x] += sum_ph Wy[ph][y] * (sum_pw G[ph][pw] *
-// Wx[pw][x]), so a wave first contracts the RoI's 7 x 7 gradients of its channel over the bins' columns
-// (T[ph] per lane = column x; G broadcast with v_readlane) and then walks the RoI's rows (Wy of the row broadcast the
-// same way; rows no sample touches are skipped).  The axis records of a batch of RoIs (taps and weights of the two
-// samples of each of the 7 + 7 bins, the forward's expressions) are built once per workgroup in LDS, one RoI per wave.
-__global__ void __launch_bounds__(1024)
+// One RoI, two channels.  Lane = (q = lane / 16, li = lane % 16).  Per block of 16 columns, lane (q, li) contracts
+// G[q][.] and G[q + 4][.] with the weights of column xb + li: T[q][x], T[q + 4][x] -- which is the B operand of
+// v_mfma_f32_16x16x4_f32 (B[k][j] in lane j + 16 k).  Per block of 16 rows the A operand is Wy^T: lane (q, li) reads
+// Wy[q][rb + li] and Wy[q + 4][rb + li] from the row table (entry 7 of a row is zero), and two MFMAs per channel leave
+// D[row][x] = sum_ph Wy[ph][row] T[ph][x] as four rows rb + 4 q + v per lane, added to the cells; rows / columns outside
+// the footprint go to a dummy cell.
+__device__ __forceinline__ void rab_scatter(const RabG &g, const float *s_tab, int e_off, int e_ymin, int e_ny, int e_xmin,
+                                            int e_nx, int W, int q, int li, f32x2 *plane, f32x2 *dummy)
+{
+    for (int xb = 0; xb < e_nx; xb += 16) {
+        const int xc = xb + li;
+        const float4 *wt = (const float4 *)s_tab + (e_off + e_ny + min(xc, e_nx - 1)) * 2;
+        const float4 wa = wt[0], wb = wt[1];
+        float t00, t01, t10, t11; // T[q] and T[q + 4] of channel 0, of channel 1
+        t00 = g.a0.x * wa.x; t10 = g.b0.x * wa.x; t01 = g.a2.x * wa.x; t11 = g.b2.x * wa.x;
+#define RAB_T(GA, GB_, GC, GD, WV)                                                                         \
+    t00 = __builtin_fmaf(GA, WV, t00); t10 = __builtin_fmaf(GB_, WV, t10);                                 \
+    t01 = __builtin_fmaf(GC, WV, t01); t11 = __builtin_fmaf(GD, WV, t11);
+        RAB_T(g.a0.y, g.b0.y, g.a2.y, g.b2.y, wa.y)
+        RAB_T(g.a0.z, g.b0.z, g.a2.z, g.b2.z, wa.z)
+        RAB_T(g.a0.w, g.b0.w, g.a2.w, g.b2.w, wa.w)
+        RAB_T(g.a1.x, g.b1.x, g.a3.x, g.b3.x, wb.x)
+        RAB_T(g.a1.y, g.b1.y, g.a3.y, g.b3.y, wb.y)
+        RAB_T(g.a1.z, g.b1.z, g.a3.z, g.b3.z, wb.z)
+#undef RAB_T
+        t01 = q < 3 ? t01 : 0.0f;
+        t11 = q < 3 ? t11 : 0.0f;
+        const bool col_ok = xc < e_nx;
+        for (int rb = 0; rb < e_ny; rb += 16) {
+            const float *ap = s_tab + (e_off + min(rb + li, e_ny - 1)) * 8 + q;
+#if RAB_EXP == 3 // speed probe: no row-weight reads
+            const float alo = (float)(rb + q), ahi = (float)li;
+            if (rb == 12345) (void)*(volatile const float *)ap;
+#else
+            const float alo = ap[0], ahi = ap[4];
+#endif
+            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t00, z, 0, 0, 0);
+            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t10, z, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t01, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t11, acc1, 0, 0, 0);
+            const int row0 = rb + 4 * q;
+            f32x2 *cell = plane + (e_ymin + row0) * W + e_xmin + xc;
+#if RAB_EXP == 2 // speed probe: no read-modify-write of the planes
+            if (acc0.x == 12345.678f) *cell = (f32x2){acc0.x + acc0.y + acc0.z + acc0.w, acc1.x + acc1.y + acc1.z + acc1.w};
+#else
+            f32x2 *p0 = col_ok && row0 + 0 < e_ny ? cell : dummy;
+            f32x2 *p1 = col_ok && row0 + 1 < e_ny ? cell + W : dummy;
+            f32x2 *p2 = col_ok && row0 + 2 < e_ny ? cell + 2 * W : dummy;
+            f32x2 *p3 = col_ok && row0 + 3 < e_ny ? cell + 3 * W : dummy;
+            const f32x2 o0 = *p0, o1 = *p1, o2 = *p2, o3 = *p3;
+            *p0 = o0 + (f32x2){acc0.x, acc1.x};
+            *p1 = o1 + (f32x2){acc0.y, acc1.y};
+            *p2 = o2 + (f32x2){acc0.z, acc1.z};
+            *p3 = o3 + (f32x2){acc0.w, acc1.w};
+#endif
+        }
+    }
+}
+
+// Workgroup = (image, chunk of 2 nw channels, RoI split), nw waves: WAVE w OWNS CHANNELS c0 + 2w, c0 + 2w + 1 and
+// their gradient planes in LDS (interleaved: one float2 per cell), so no two waves ever add into the same plane, and
+// inside a wave the lanes are distinct CELLS of the RoI's footprint: the scatter needs no atomics, it is ds_read_b64,
+// add, ds_write_b64.  (LDS float atomics are what the first version used: ds_add_f32 costs ~130 cycles per wave
+// instruction on gfx950 whether or not lanes collide -- 68 ms at the headline shape.)
+//
+// RoIAlign's weights are separable: grad_feat[y][x] += sum_ph Wy[ph][y] * (sum_pw G[ph][pw] * Wx[pw][x]), Wy / Wx =
+// the weight that the two samples of bin row ph / column pw put on cell row y / column x.  Per RoI the workgroup
+// builds both as TABLES in LDS once (an entry = the 7 weights of one cell row or column; rows carry the 1/4 of the
+// 2 x 2 average), for as many RoIs at a time as the table space holds; every wave then walks those RoIs for its two
+// channels (rab_scatter: the column contraction on the VALU, 14 FMAs per channel and 16 columns instead of 49; the
+// row contraction as two 16 x 16 x 4 fp32 MFMAs per channel and 16 x 16 cells; grad_out of the next three RoIs in
+// flight, because a wave's RoIs are a serial chain of dependent loads otherwise: 4.9 -> 2.8 ms without the loads).
+// HBM sees grad_out once plus one write of the planes; one workgroup per (image, chunk) -> deterministic sums.
+#define RAB_TAB_MAX_ENTRIES 2048
+__global__ void __launch_bounds__(512)
 roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H, int W,
                                 const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
                                 float scale, int level, int n_levels, int k_min, int k_max, int chunks,
-                                int splits, int B, float *__restrict__ grad_feat)
+                                int splits, int B, int tab_off, int cap, float *__restrict__ grad_feat)
 {
-    extern __shared__ float s_g[]; // [nw][H * W]
-    __shared__ int2 s_ri[16 * 16];    // per RoI of the batch: records 0..6 rows, 8..14 columns: lo of the two samples
-    __shared__ float4 s_rw[16 * 16];  // their weights (rows carry the 1/4 of the 2 x 2 average)
-    __shared__ int4 s_rng[16];        // ymin, ymax, xmin, xmax of the RoI's taps (ymin > ymax: nothing to do)
+    extern __shared__ __align__(16) float s_dyn[]; // [nw][H * W] float2 planes, then the tables: cap entries of 8 floats
     __shared__ int s_off, s_cnt;
+    __shared__ f32x2 s_dummy[8]; // per wave: where the masked lanes of a block add
+    f32x2 *const s_pl = (f32x2 *)s_dyn;
+    float *const s_tab = s_dyn + tab_off;
     const int nw = blockDim.x >> 6;
     const int chunk = blockIdx.x % chunks;
     const int grp = blockIdx.x / chunks;
     const int split = grp % splits;
     const int b = grp / splits;
-    const int c0 = chunk * nw;
-    const int nc = min(nw, C - c0);
+    const int c0 = chunk * 2 * nw;
+    const int nc = min(2 * nw, C - c0);
     const int HW = H * W;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -82,101 +190,129 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
         }
         s_off = off;
     }
-    for (int t = threadIdx.x; t < nw * HW; t += blockDim.x) s_g[t] = 0.0f;
+    for (int t = threadIdx.x; t < nw * HW; t += blockDim.x) s_pl[t] = (f32x2){0.0f, 0.0f};
     __syncthreads();
     const int cnt = s_cnt;
     const int per = (cnt + splits - 1) / splits;
     const int j_end = min(cnt, (split + 1) * per);
     const float4 *pb = props + (long long)b * P;
-    float *plane = s_g + wave * HW;
-    const float *gb = grad_out + ((long long)s_off * C + c0 + wave) * 49;
-    for (int j0 = split * per; j0 < j_end; j0 += nw) {
-        __syncthreads(); // the previous batch's records have been used
-        {
-            // ---- records of RoI j0 + wave: lanes 0..6 its bin rows, lanes 8..14 its bin columns
-            const int j = j0 + wave;
-            bool live = j < j_end;
-            float4 rec = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
-            if (live) {
-                const float4 box = pb[j];
-                if (n_levels > 1 && map_level(box, k_min, k_max) != level) live = false;
-                rec = rab_record(box, scale);
-            }
-            if (lane < 16) {
-                const int axis = lane >> 3, p = lane & 7;
-                const float start = axis ? rec.x : rec.y, bin = axis ? rec.z : rec.w;
-                const int n = axis ? W : H;
-                const AxisSample a0 = axis_sample(start + (float)p * bin + (0.0f + 0.5f) * bin / 2.0f, n);
-                const AxisSample a1 = axis_sample(start + (float)p * bin + (1.0f + 0.5f) * bin / 2.0f, n);
-                const float k = axis ? 1.0f : 0.25f;
-                const bool rec_ok = live && p < 7;
-                // (an invalid sample: a lo that no cell is near)
-                s_ri[wave * 16 + lane] = make_int2(a0.ok ? a0.lo : -0x40000000, a1.ok ? a1.lo : -0x40000000);
-                s_rw[wave * 16 + lane] = make_float4(a0.wlo * k, a0.whi * k, a1.wlo * k, a1.whi * k);
-                // first and last tap of the axis: samples grow with (bin, sample), so a min / max over the 7 bins
-                int tmin = rec_ok ? (a0.ok ? a0.lo : (a1.ok ? a1.lo : 0x7FFFFFFF)) : 0x7FFFFFFF;
-                int tmax = rec_ok ? (a1.ok ? a1.hi : (a0.ok ? a0.hi : -1)) : -1;
-#pragma unroll
-                for (int o = 4; o >= 1; o >>= 1) { // lanes 0..7 and 8..15 reduce among themselves
-                    tmin = min(tmin, __shfl_xor(tmin, o));
-                    tmax = max(tmax, __shfl_xor(tmax, o));
-                }
-                const int xmin = __shfl(tmin, 8), xmax = __shfl(tmax, 8);
-                if (lane == 0) {
-                    const bool any = tmin <= tmax && xmin <= xmax;
-                    s_rng[wave] = any ? make_int4(tmin, tmax, xmin, xmax) : make_int4(1, 0, 1, 0);
-                }
-            }
+    f32x2 *const plane = s_pl + wave * HW;
+    const int ch0 = c0 + 2 * wave;
+    const bool has0 = ch0 < C, has1 = ch0 + 1 < C;
+    const float *gb = grad_out + ((long long)s_off * C + min(ch0, C - 1)) * 49;
+    const int q = lane >> 4, li = lane & 15;
+    const int ch1_off = has1 ? 49 : 0;
+    f32x2 *const dummy = s_dummy + wave;
+    for (int jw = split * per; jw < j_end; jw += 64) {
+        // ---- lane = candidate RoI jw + lane: footprint and table size (every wave computes the same values)
+        bool live = jw + lane < j_end;
+        float4 rec = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
+        int ymin = 0, ymax = 0, xmin = 0, xmax = 0;
+        if (live) {
+            const float4 box = pb[jw + lane];
+            if (n_levels > 1 && map_level(box, k_min, k_max) != level) live = false;
+            rec = rab_record(box, scale);
         }
-        __syncthreads();
-        if (wave >= nc) continue; // (a chunk's tail: this wave has no channel, it only helped with the records)
-        const int nb = min(nw, j_end - j0);
-        for (int e = 0; e < nb; ++e) {
-            const int4 rng = s_rng[e];
-            if (rng.x > rng.y) continue; // not this level's RoI, or every sample outside the map
-            const float g = lane < 49 ? gb[(long long)(j0 + e) * C * 49 + lane] : 0.0f;
-            for (int yb = rng.x; yb <= rng.y; yb += 64) {
-                // this lane's row weights: row yb + lane against the 7 row records
-                float wy[7];
+        live = axis_range(rec.y, rec.w, H, ymin, ymax) && live;
+        live = axis_range(rec.x, rec.z, W, xmin, xmax) && live;
+        const int ny = ymax - ymin + 1, nx = xmax - xmin + 1;
+        const int ent = live ? ny + nx : 0; // <= H + W <= cap
+        int pre = ent; // inclusive prefix over the lanes
 #pragma unroll
-                for (int ph = 0; ph < 7; ++ph) wy[ph] = axis_weight(s_ri[e * 16 + ph], s_rw[e * 16 + ph], yb + lane);
-                for (int xb = rng.z; xb <= rng.w; xb += 64) {
-                    const int x = xb + lane;
-                    float wx[7];
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pre, o);
+            pre += lane >= o ? t : 0;
+        }
+        const int n_cand = min(64, j_end - jw);
+        int done = 0, base = 0;
+        while (done < n_cand) {
+            // ---- the batch: candidates done .. done + m - 1, as many as the table space holds (at least one)
+            const unsigned long long fit = __ballot(lane >= done && pre - base <= cap);
+            const unsigned long long miss = ~fit >> done;
+            int m = miss ? __ffsll((long long)miss) - 1 : 64 - done;
+            m = min(m, n_cand - done);
+            const int my_off = pre - ent - base; // first entry of this lane's RoI
+            __syncthreads(); // the previous batch's tables have been used
+            for (int g = wave * 4; g < m; g += nw * 4) {
+                // ---- tables of RoIs done + g .. + 3: 16 lanes per RoI, lane = (axis, bin) for the scatter
+                const int src = min(done + g + (lane >> 4), 63);
+                const bool mine = g + (lane >> 4) < m;
+                const int src_ent = __shfl(ent, src); // (every lane takes part: the source lanes are anywhere in the wave)
+                const int e_ent = mine ? src_ent : 0;
+                const int e_off = __shfl(my_off, src);
+                const int e_ymin = __shfl(ymin, src), e_ny = __shfl(ny, src), e_xmin = __shfl(xmin, src);
+                const float e_sx = __shfl(rec.x, src), e_sy = __shfl(rec.y, src);
+                const float e_bw = __shfl(rec.z, src), e_bh = __shfl(rec.w, src);
+                float4 *t4 = (float4 *)s_tab + e_off * 2;
+                for (int i = lane & 15; i < e_ent * 2; i += 16) t4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int axis = (lane >> 3) & 1, p = lane & 7;
+                if (e_ent > 0 && p < 7) {
+                    const float start = axis ? e_sx : e_sy, bin = axis ? e_bw : e_bh;
+                    const float k = axis ? 1.0f : 0.25f;
+                    float *col = s_tab + (e_off + (axis ? e_ny - e_xmin : -e_ymin)) * 8 + p;
 #pragma unroll
-                    for (int pw = 0; pw < 7; ++pw) wx[pw] = axis_weight(s_ri[e * 16 + 8 + pw], s_rw[e * 16 + 8 + pw], x);
-                    float T[7];
-#pragma unroll
-                    for (int ph = 0; ph < 7; ++ph) {
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int pw = 0; pw < 7; ++pw) acc += lane_get(g, ph * 7 + pw) * wx[pw];
-                        T[ph] = acc;
-                    }
-                    // rows that some sample touches (lane = row): the others are not visited at all
-                    unsigned long long rows = __ballot(wy[0] != 0.0f || wy[1] != 0.0f || wy[2] != 0.0f || wy[3] != 0.0f ||
-                                                       wy[4] != 0.0f || wy[5] != 0.0f || wy[6] != 0.0f);
-                    while (rows != 0) {
-                        const int r = __ffsll((long long)rows) - 1;
-                        rows &= rows - 1;
-                        float d = 0.0f;
-#pragma unroll
-                        for (int ph = 0; ph < 7; ++ph) d += lane_get(wy[ph], r) * T[ph];
-                        if (x <= rng.w) plane[(yb + r) * W + x] += d;
+                    for (int s = 0; s < 2; ++s) {
+                        const AxisSample a = axis_sample(start + (float)p * bin + ((float)s + 0.5f) * bin / 2.0f, axis ? W : H);
+                        if (a.ok) { // (a sample outside the map sends nothing)
+                            col[a.lo * 8] += a.wlo * k;
+                            col[a.hi * 8] += a.whi * k;
+                        }
                     }
                 }
             }
+            __syncthreads();
+            if (has0) {
+                // ---- this wave's two channels over the batch's RoIs, grad_out of the next three RoIs in flight
+                unsigned long long todo = __ballot(ent > 0) & (m >= 64 ? ~0ull : (((1ull << m) - 1ull) << done));
+                auto next = [&]() -> int {
+                    if (!todo) return -1;
+                    const int e = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    return e;
+                };
+                const int e_first = next();
+                if (e_first >= 0) {
+                    RabG GA, GB, GC;
+                    int eA = e_first, eB = next(), eC = next();
+                    rab_load(GA, gb, jw + eA, C, q, ch1_off);
+                    rab_load(GB, gb, jw + (eB >= 0 ? eB : e_first), C, q, ch1_off);
+                    rab_load(GC, gb, jw + (eC >= 0 ? eC : e_first), C, q, ch1_off);
+#define RAB_STEP(G, E)                                                                                              \
+    {                                                                                                               \
+        const int e_off = __builtin_amdgcn_readlane(my_off, E);                                                     \
+        const int e_ymin = __builtin_amdgcn_readlane(ymin, E), e_ny = __builtin_amdgcn_readlane(ny, E);            \
+        const int e_xmin = __builtin_amdgcn_readlane(xmin, E), e_nx = __builtin_amdgcn_readlane(nx, E);            \
+        rab_scatter(G, s_tab, e_off, e_ymin, e_ny, e_xmin, e_nx, W, q, li, plane, dummy);                           \
+        E = next();                                                                                                 \
+        rab_load(G, gb, jw + (E >= 0 ? E : e_first), C, q, ch1_off);                                                \
+    }
+                    while (true) {
+                        RAB_STEP(GA, eA)
+                        if (eB < 0) break;
+                        RAB_STEP(GB, eB)
+                        if (eC < 0) break;
+                        RAB_STEP(GC, eC)
+                        if (eA < 0) break;
+                    }
+#undef RAB_STEP
+                }
+            }
+            base = __builtin_amdgcn_readlane(pre, done + m - 1);
+            done += m;
         }
     }
     __syncthreads();
     float *out = grad_feat + ((long long)b * C + c0) * HW;
-    if (splits == 1) {
-        for (int t = threadIdx.x; t < nc * HW; t += blockDim.x) out[t] = s_g[t];
-    } else {
-        for (int t = threadIdx.x; t < nc * HW; t += blockDim.x) {
-            const float v = s_g[t];
-            if (v != 0.0f) unsafeAtomicAdd(out + t, v);
-        }
+    const float *s_f = (const float *)s_pl;
+    for (int t = threadIdx.x; t < nc * HW; t += blockDim.x) {
+        const int c = t / HW, cellidx = t - c * HW;
+        const float v = s_f[((c >> 1) * HW + cellidx) * 2 + (c & 1)];
+        if (splits == 1)
+            out[t] = v;
+        else if (v != 0.0f)
+            unsafeAtomicAdd(out + t, v);
     }
 }
 
@@ -258,13 +394,14 @@ extern "C" int frcnn_roi_align_batched_backward_f32(const float *grad_out, int B
         return FRCNN_OK;
     }
     FRCNN_REQUIRE(grad_out && props, "roi_align_backward: null pointer");
-    const long long plane_bytes = (long long)H * W * 4;
-    // planes in LDS, one wave per channel: worth it from four channels (waves) per workgroup on
-    if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && plane_bytes * 4 <= RAB_LDS_BUDGET &&
-        (long long)P * 49 < (1ll << 30)) {
-        int CC = (int)(RAB_LDS_BUDGET / plane_bytes);
-        if (CC > 16) CC = 16;
-        if (CC > C) CC = C;
+    // planes in LDS, one wave per channel pair: worth it from two waves (four channels) per workgroup on
+    const long long pair_bytes = (long long)H * W * 8;
+    const long long tab_min = (long long)(H + W) * 32 > 8192 ? (long long)(H + W) * 32 : 8192;
+    int nw = 8;
+    while (nw >= 2 && nw * pair_bytes + 16 + tab_min > RAB_LDS_BUDGET) --nw;
+    if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && nw >= 2 && (long long)P * 49 < (1ll << 30)) {
+        if (2 * nw > C) nw = (C + 1) / 2;
+        const int CC = 2 * nw;
         const int chunks = (C + CC - 1) / CC;
         // one workgroup per (image, chunk) when that fills the chip; else split the RoIs and add the planes up
         int splits = 1;
@@ -276,14 +413,18 @@ extern "C" int frcnn_roi_align_batched_backward_f32(const float *grad_out, int B
             hipError_t e = hipMemsetAsync(grad_feat, 0, plane_elems * sizeof(float), st);
             FRCNN_REQUIRE(e == hipSuccess, "roi_align_backward: memset failed: %s", hipGetErrorString(e));
         }
-        const size_t lds = (size_t)plane_bytes * (size_t)CC;
+        const int tab_off = (int)(((long long)nw * H * W * 2 + 3) / 4 * 4); // floats; the tables start 16-byte aligned
+        long long cap = (RAB_LDS_BUDGET - (long long)tab_off * 4) / 32;
+        if (cap > RAB_TAB_MAX_ENTRIES) cap = RAB_TAB_MAX_ENTRIES;
+        FRCNN_REQUIRE(cap >= H + W, "roi_align_backward: internal: table space %lld < %d entries", cap, H + W);
+        const size_t lds = (size_t)tab_off * 4 + (size_t)cap * 32;
         static size_t granted[FRCNN_MAX_DEVICES];
         hipError_t e = frcnn_reserve_dynamic_lds((const void *)roi_align_plane_backward_kernel, lds, granted);
         FRCNN_REQUIRE(e == hipSuccess, "roi_align_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         FRCNN_REQUIRE((long long)B * chunks * splits < (1ll << 31), "roi_align_backward: grid too large");
-        hipLaunchKernelGGL(roi_align_plane_backward_kernel, dim3((unsigned)(B * chunks * splits)), dim3(64 * CC),
+        hipLaunchKernelGGL(roi_align_plane_backward_kernel, dim3((unsigned)(B * chunks * splits)), dim3(64 * nw),
                            lds, st, grad_out, C, H, W, (const float4 *)props, count, P, spatial_scale, level,
-                           n_levels, k_min, k_max, chunks, splits, B, grad_feat);
+                           n_levels, k_min, k_max, chunks, splits, B, tab_off, (int)cap, grad_feat);
         FRCNN_CHECK_LAUNCH("roi_align_plane_backward");
         return FRCNN_OK;
     }

@@ -1440,7 +1440,8 @@ def test_closed_form_roi_pool(dev):
 
 
 # ---- RoIAlign backward (ROIHead/roi_head.py:127-130 under autograd: the RoI losses train the backbone) -----------
-@pytest.mark.parametrize("case", ["headline_map", "tail_channels_small_batch", "pyramid_with_oversize_plane"])
+@pytest.mark.parametrize("case", ["headline_map", "tail_channels_small_batch", "pyramid_with_oversize_plane",
+                                  "one_workgroup_per_chunk"])
 def test_roi_align_backward_vs_oracle(dev, oracle, case):
     """d(sum(out * G)) / d(features) through MultiScaleRoIAlign: the HIP backward (LDS-atomic plane kernel, the
     RoI-split form for small batches, the global-atomic fallback for planes beyond LDS) against the oracle's
@@ -1452,6 +1453,9 @@ def test_roi_align_backward_vs_oracle(dev, oracle, case):
         B, C, img, fsz, n = 3, 20, (600, 1000), [(37, 62)], [300, 1, 120]
     elif case == "tail_channels_small_batch":
         B, C, img, fsz, n = 1, 7, (256, 320), [(32, 40)], [64]
+    elif case == "one_workgroup_per_chunk":
+        # B * chunks >= 256: no RoI split, plain stores; hundreds of RoIs per workgroup = several table batches
+        B, C, img, fsz, n = 8, 515, (384, 640), [(24, 40)], [260, 3, 150, 200, 64, 65, 129, 300]
     else:
         B, C, img, fsz, n = 2, 3, (800, 1344), [(200, 336), (100, 168), (50, 84), (25, 42)], [150, 90]
     names = [str(i) for i in range(len(fsz))]
