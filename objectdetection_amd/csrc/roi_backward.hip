@@ -5,20 +5,21 @@
 // roi_align_backward), samples outside [-1, H] x [-1, W] send nothing, boxes get no gradient.
 //
 // torchvision scatters with one global float atomic per tap (16 per output element).  Here a workgroup owns
-// (image, channel chunk, RoI split) and keeps the chunk's GRADIENT PLANES in LDS, one wave per channel, and the
-// scatter needs no atomics (see roi_align_plane_backward_kernel); HBM sees grad_out once plus one write of the
-// planes, and with one workgroup per (image, chunk) the result is deterministic.  Planes too large for four
-// channels of them to fit LDS (FPN P3 / P2 at 800 x 1344) fall back to global atomics, whose sum order is not
-// fixed (as in torchvision).
+// (image, channel chunk, RoI split) and keeps the chunk's GRADIENT PLANES in LDS, one wave per channel pair, and the
+// scatter needs no atomics: RoIAlign's weights are separable, so per RoI the update of a channel is Wy^T (G Wx), two
+// small matrix products that run on the fp32 MFMA (see roi_align_plane_backward_kernel); HBM sees grad_out once plus
+// one write of the planes, and with one workgroup per (image, chunk) the result is deterministic.  Planes too large
+// for four channels of them to fit LDS (FPN P3 / P2 at 800 x 1344) fall back to global atomics, whose sum order is
+// not fixed (as in torchvision).
 #include <math.h>
 
 #include "common.h"
 #include "roi_common.h"
 
-#ifndef RAB_EXP
-#define RAB_EXP 0
+#ifndef RAB_DEPTH
+#define RAB_DEPTH 6 // RoIs whose grad_out is in flight per wave
 #endif
-#define RAB_LDS_BUDGET (160 * 1024 - 256) // dynamic LDS of the plane kernel: planes + tables
+#define RAB_LDS_BUDGET (160 * 1024 - 1024) // dynamic LDS of the plane kernel: planes + tables
 
 __device__ __forceinline__ float4 rab_record(float4 box, float scale)
 {
@@ -30,8 +31,6 @@ __device__ __forceinline__ float4 rab_record(float4 box, float scale)
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4))); // a 16-byte load from a 4-byte-aligned address
-typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
 
 // The cells that the 14 samples of an axis touch: samples grow with (bin, sample), so the first tap of the first
 // valid sample and the last tap of the last valid one bound them.  False when every sample is outside [-1, n].
@@ -56,80 +55,76 @@ __device__ __forceinline__ bool axis_range(float start, float bin, int n, int &c
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// grad_out of one RoI as the lanes of a wave hold it: rows q and q + 4 of the 7 x 7 block (q = lane / 16), both
-// channels; lanes q = 3 have no second row and load the first one again (never used: their T is forced to zero).
+// grad_out of one RoI as the A operand of the column contraction (v_mfma_f32_16x16x4_f32: A[i][k] in lane i + 16 k):
+// row i = 4 g + v stands for (channel v / 2, bin row ph = g + 4 (v % 2)), k for bin column pw = k (lo) and k + 4 (hi);
+// rows and columns that do not exist (ph = 7, pw = 7) are zero.  Two dword loads per lane and RoI, each wave
+// instruction a gather inside two 196-byte runs.
 struct RabG {
-    f32x4u a0, b0, a2, b2;
-    f32x3u a1, b1, a3, b3;
+    float lo, hi;
 };
 
-__device__ __forceinline__ void rab_load(RabG &g, const float *__restrict__ gb, int j, int C, int q, int ch1_off)
+struct RabLane { // per-lane constants of the gather
+    int off_lo, off_hi;
+    bool ok_lo, ok_hi;
+};
+
+__device__ __forceinline__ RabLane rab_lane(int lane, int ch1_off)
 {
-    const float *gp = gb + (long long)j * C * 49 + q * 7;
-    const float *gq = gp + ch1_off; // (a missing second channel computes on the first one's data into the unused half of the cells)
-    const int o2 = q < 3 ? 28 : 0;
-#if RAB_EXP == 1 // speed probe: no grad_out loads
-    const float fz = (float)(j + o2) + (gp == gq ? 1.0f : 0.0f);
-    g.a0 = g.b0 = g.a2 = g.b2 = (f32x4u){fz, fz, fz, fz};
-    g.a1 = g.b1 = g.a3 = g.b3 = (f32x3u){fz, fz, fz};
-#else
-    g.a0 = *(const f32x4u *)gp;
-    g.b0 = *(const f32x4u *)gq;
-    g.a1 = *(const f32x3u *)(gp + 4);
-    g.b1 = *(const f32x3u *)(gq + 4);
-    g.a2 = *(const f32x4u *)(gp + o2);
-    g.b2 = *(const f32x4u *)(gq + o2);
-    g.a3 = *(const f32x3u *)(gp + o2 + 4);
-    g.b3 = *(const f32x3u *)(gq + o2 + 4);
-#endif
+    const int i = lane & 15, k = lane >> 4;
+    const int v = i & 3, ph = (i >> 2) + 4 * (v & 1);
+    RabLane L;
+    L.ok_lo = ph < 7;
+    L.ok_hi = ph < 7 && k < 3;
+    const int row = (v >> 1) * ch1_off + (L.ok_lo ? ph : 0) * 7;
+    L.off_lo = row + k;
+    L.off_hi = row + (L.ok_hi ? k + 4 : k);
+    return L;
 }
 
-// One RoI, two channels.  Lane = (q = lane / 16, li = lane % 16).  Per block of 16 columns, lane (q, li) contracts
-// G[q][.] and G[q + 4][.] with the weights of column xb + li: T[q][x], T[q + 4][x] -- which is the B operand of
-// v_mfma_f32_16x16x4_f32 (B[k][j] in lane j + 16 k).  Per block of 16 rows the A operand is Wy^T: lane (q, li) reads
-// Wy[q][rb + li] and Wy[q + 4][rb + li] from the row table (entry 7 of a row is zero), and two MFMAs per channel leave
-// D[row][x] = sum_ph Wy[ph][row] T[ph][x] as four rows rb + 4 q + v per lane, added to the cells; rows / columns outside
-// the footprint go to a dummy cell.
-__device__ __forceinline__ void rab_scatter(const RabG &g, const float *s_tab, int e_off, int e_ymin, int e_ny, int e_xmin,
-                                            int e_nx, int W, int q, int li, f32x2 *plane, f32x2 *dummy)
+__device__ __forceinline__ void rab_load(RabG &g, const float *__restrict__ gb, int j, int C, const RabLane &L)
 {
+    const float *gp = gb + (long long)j * C * 49;
+    // Issued by hand and waited for by hand (rab_wait): the compiler's own counter bookkeeping gives up on a rotating
+    // set of loads in a loop with exits and waits for ALL of them before every second RoI.
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(g.lo) : "v"(L.off_lo * 4), "s"(gp));
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(g.hi) : "v"(L.off_hi * 4), "s"(gp));
+}
+
+// The loads of `g` are followed by those of RAB_DEPTH - 1 other RoIs, two each, and loads return in order.
+__device__ __forceinline__ void rab_wait(RabG &g)
+{
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g.lo), "+v"(g.hi) : "n"(2 * (RAB_DEPTH - 1)));
+}
+
+// One RoI, two channels, lane = (q = lane / 16, li = lane % 16).  Per block of 16 columns: B = Wx (lane (q, li) reads
+// Wx[q][xb + li] and Wx[q + 4][xb + li] from the column table; entry 7 is zero), two MFMAs leave
+// T[ph][x] = sum_pw G[ph][pw] Wx[pw][x] as D rows, i.e. lane (q, li) holds T[q][x], T[q + 4][x] of channel 0 and of
+// channel 1 -- which is the B operand layout of the row contraction (B[k][j] in lane j + 16 k).  Per block of 16 rows:
+// A = Wy^T (lane (q, li) reads Wy[q][rb + li], Wy[q + 4][rb + li] from the row table), two MFMAs per channel leave
+// D[row][x] = sum_ph Wy[ph][row] T[ph][x] as four rows rb + 4 q + v per lane, added to the cells; rows / columns
+// outside the footprint go to a dummy cell.
+__device__ __forceinline__ void rab_scatter(const RabG &g, const RabLane &L, const float *s_tab, int e_off, int e_ymin,
+                                            int e_ny, int e_xmin, int e_nx, int W, int q, int li, int lane_rel, f32x2 *plane,
+                                            f32x2 *dummy)
+{
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x2 *const lane_cell = plane + lane_rel; // lane_rel = 4 q W + li
+    const float glo = L.ok_lo ? g.lo : 0.0f, ghi = L.ok_hi ? g.hi : 0.0f;
     for (int xb = 0; xb < e_nx; xb += 16) {
         const int xc = xb + li;
-        const float4 *wt = (const float4 *)s_tab + (e_off + e_ny + min(xc, e_nx - 1)) * 2;
-        const float4 wa = wt[0], wb = wt[1];
-        float t00, t01, t10, t11; // T[q] and T[q + 4] of channel 0, of channel 1
-        t00 = g.a0.x * wa.x; t10 = g.b0.x * wa.x; t01 = g.a2.x * wa.x; t11 = g.b2.x * wa.x;
-#define RAB_T(GA, GB_, GC, GD, WV)                                                                         \
-    t00 = __builtin_fmaf(GA, WV, t00); t10 = __builtin_fmaf(GB_, WV, t10);                                 \
-    t01 = __builtin_fmaf(GC, WV, t01); t11 = __builtin_fmaf(GD, WV, t11);
-        RAB_T(g.a0.y, g.b0.y, g.a2.y, g.b2.y, wa.y)
-        RAB_T(g.a0.z, g.b0.z, g.a2.z, g.b2.z, wa.z)
-        RAB_T(g.a0.w, g.b0.w, g.a2.w, g.b2.w, wa.w)
-        RAB_T(g.a1.x, g.b1.x, g.a3.x, g.b3.x, wb.x)
-        RAB_T(g.a1.y, g.b1.y, g.a3.y, g.b3.y, wb.y)
-        RAB_T(g.a1.z, g.b1.z, g.a3.z, g.b3.z, wb.z)
-#undef RAB_T
-        t01 = q < 3 ? t01 : 0.0f;
-        t11 = q < 3 ? t11 : 0.0f;
+        const float *wp = s_tab + (e_off + e_ny + min(xc, e_nx - 1)) * 8 + q;
+        f32x4 t = __builtin_amdgcn_mfma_f32_16x16x4f32(glo, wp[0], z, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x4f32(ghi, wp[4], t, 0, 0, 0);
         const bool col_ok = xc < e_nx;
         for (int rb = 0; rb < e_ny; rb += 16) {
             const float *ap = s_tab + (e_off + min(rb + li, e_ny - 1)) * 8 + q;
-#if RAB_EXP == 3 // speed probe: no row-weight reads
-            const float alo = (float)(rb + q), ahi = (float)li;
-            if (rb == 12345) (void)*(volatile const float *)ap;
-#else
             const float alo = ap[0], ahi = ap[4];
-#endif
-            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t00, z, 0, 0, 0);
-            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t10, z, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t01, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t11, acc1, 0, 0, 0);
+            f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t.x, z, 0, 0, 0);
+            f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t.z, z, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t.w, acc1, 0, 0, 0);
             const int row0 = rb + 4 * q;
-            f32x2 *cell = plane + (e_ymin + row0) * W + e_xmin + xc;
-#if RAB_EXP == 2 // speed probe: no read-modify-write of the planes
-            if (acc0.x == 12345.678f) *cell = (f32x2){acc0.x + acc0.y + acc0.z + acc0.w, acc1.x + acc1.y + acc1.z + acc1.w};
-#else
+            f32x2 *cell = lane_cell + ((e_ymin + rb) * W + e_xmin + xb);
             f32x2 *p0 = col_ok && row0 + 0 < e_ny ? cell : dummy;
             f32x2 *p1 = col_ok && row0 + 1 < e_ny ? cell + W : dummy;
             f32x2 *p2 = col_ok && row0 + 2 < e_ny ? cell + 2 * W : dummy;
@@ -139,7 +134,6 @@ __device__ __forceinline__ void rab_scatter(const RabG &g, const float *s_tab, i
             *p1 = o1 + (f32x2){acc0.y, acc1.y};
             *p2 = o2 + (f32x2){acc0.z, acc1.z};
             *p3 = o3 + (f32x2){acc0.w, acc1.w};
-#endif
         }
     }
 }
@@ -148,15 +142,15 @@ __device__ __forceinline__ void rab_scatter(const RabG &g, const float *s_tab, i
 // their gradient planes in LDS (interleaved: one float2 per cell), so no two waves ever add into the same plane, and
 // inside a wave the lanes are distinct CELLS of the RoI's footprint: the scatter needs no atomics, it is ds_read_b64,
 // add, ds_write_b64.  (LDS float atomics are what the first version used: ds_add_f32 costs ~130 cycles per wave
-// instruction on gfx950 whether or not lanes collide -- 68 ms at the headline shape.)
+// instruction on gfx950 whether or not lanes collide -- 68 ms at the headline shape, against 3.4 ms for this form.)
 //
 // RoIAlign's weights are separable: grad_feat[y][x] += sum_ph Wy[ph][y] * (sum_pw G[ph][pw] * Wx[pw][x]), Wy / Wx =
 // the weight that the two samples of bin row ph / column pw put on cell row y / column x.  Per RoI the workgroup
 // builds both as TABLES in LDS once (an entry = the 7 weights of one cell row or column; rows carry the 1/4 of the
 // 2 x 2 average), for as many RoIs at a time as the table space holds; every wave then walks those RoIs for its two
-// channels (rab_scatter: the column contraction on the VALU, 14 FMAs per channel and 16 columns instead of 49; the
-// row contraction as two 16 x 16 x 4 fp32 MFMAs per channel and 16 x 16 cells; grad_out of the next three RoIs in
-// flight, because a wave's RoIs are a serial chain of dependent loads otherwise: 4.9 -> 2.8 ms without the loads).
+// channels (rab_scatter: both contractions as 16 x 16 x 4 fp32 MFMAs, the column one for the two channels at once;
+// grad_out of the next RAB_DEPTH RoIs in flight, because a wave's RoIs are a serial chain of dependent loads
+// otherwise).
 // HBM sees grad_out once plus one write of the planes; one workgroup per (image, chunk) -> deterministic sums.
 #define RAB_TAB_MAX_ENTRIES 2048
 __global__ void __launch_bounds__(512)
@@ -167,7 +161,7 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
 {
     extern __shared__ __align__(16) float s_dyn[]; // [nw][H * W] float2 planes, then the tables: cap entries of 8 floats
     __shared__ int s_off, s_cnt;
-    __shared__ f32x2 s_dummy[8]; // per wave: where the masked lanes of a block add
+    __shared__ f32x2 s_dummy[64]; // per lane: where the masked lanes of a block add (same-address writes would serialise)
     f32x2 *const s_pl = (f32x2 *)s_dyn;
     float *const s_tab = s_dyn + tab_off;
     const int nw = blockDim.x >> 6;
@@ -201,8 +195,9 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
     const bool has0 = ch0 < C, has1 = ch0 + 1 < C;
     const float *gb = grad_out + ((long long)s_off * C + min(ch0, C - 1)) * 49;
     const int q = lane >> 4, li = lane & 15;
-    const int ch1_off = has1 ? 49 : 0;
-    f32x2 *const dummy = s_dummy + wave;
+    const int lane_rel = 4 * q * W + li;
+    const RabLane GL = rab_lane(lane, has1 ? 49 : 0);
+    f32x2 *const dummy = s_dummy + lane;
     for (int jw = split * per; jw < j_end; jw += 64) {
         // ---- lane = candidate RoI jw + lane: footprint and table size (every wave computes the same values)
         bool live = jw + lane < j_end;
@@ -264,7 +259,7 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
             }
             __syncthreads();
             if (has0) {
-                // ---- this wave's two channels over the batch's RoIs, grad_out of the next three RoIs in flight
+                // ---- this wave's two channels over the batch's RoIs, grad_out of the next RAB_DEPTH RoIs in flight
                 unsigned long long todo = __ballot(ent > 0) & (m >= 64 ? ~0ull : (((1ull << m) - 1ull) << done));
                 auto next = [&]() -> int {
                     if (!todo) return -1;
@@ -274,29 +269,31 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
                 };
                 const int e_first = next();
                 if (e_first >= 0) {
-                    RabG GA, GB, GC;
-                    int eA = e_first, eB = next(), eC = next();
-                    rab_load(GA, gb, jw + eA, C, q, ch1_off);
-                    rab_load(GB, gb, jw + (eB >= 0 ? eB : e_first), C, q, ch1_off);
-                    rab_load(GC, gb, jw + (eC >= 0 ? eC : e_first), C, q, ch1_off);
-#define RAB_STEP(G, E)                                                                                              \
-    {                                                                                                               \
-        const int e_off = __builtin_amdgcn_readlane(my_off, E);                                                     \
-        const int e_ymin = __builtin_amdgcn_readlane(ymin, E), e_ny = __builtin_amdgcn_readlane(ny, E);            \
-        const int e_xmin = __builtin_amdgcn_readlane(xmin, E), e_nx = __builtin_amdgcn_readlane(nx, E);            \
-        rab_scatter(G, s_tab, e_off, e_ymin, e_ny, e_xmin, e_nx, W, q, li, plane, dummy);                           \
-        E = next();                                                                                                 \
-        rab_load(G, gb, jw + (E >= 0 ? E : e_first), C, q, ch1_off);                                                \
-    }
-                    while (true) {
-                        RAB_STEP(GA, eA)
-                        if (eB < 0) break;
-                        RAB_STEP(GB, eB)
-                        if (eC < 0) break;
-                        RAB_STEP(GC, eC)
-                        if (eA < 0) break;
+                    RabG G[RAB_DEPTH];
+                    int E[RAB_DEPTH];
+                    E[0] = e_first;
+#pragma unroll
+                    for (int d = 1; d < RAB_DEPTH; ++d) E[d] = next();
+#pragma unroll
+                    for (int d = 0; d < RAB_DEPTH; ++d) rab_load(G[d], gb, jw + (E[d] >= 0 ? E[d] : e_first), C, GL);
+                    bool more = true;
+                    while (more) {
+#pragma unroll
+                        for (int d = 0; d < RAB_DEPTH; ++d) {
+                            if (E[d] < 0) {
+                                more = false;
+                                break;
+                            }
+                            const int e = E[d];
+                            const int e_off = __builtin_amdgcn_readlane(my_off, e);
+                            const int e_ymin = __builtin_amdgcn_readlane(ymin, e), e_ny = __builtin_amdgcn_readlane(ny, e);
+                            const int e_xmin = __builtin_amdgcn_readlane(xmin, e), e_nx = __builtin_amdgcn_readlane(nx, e);
+                            rab_wait(G[d]);
+                            rab_scatter(G[d], GL, s_tab, e_off, e_ymin, e_ny, e_xmin, e_nx, W, q, li, lane_rel, plane, dummy);
+                            E[d] = next();
+                            rab_load(G[d], gb, jw + (E[d] >= 0 ? E[d] : e_first), C, GL);
+                        }
                     }
-#undef RAB_STEP
                 }
             }
             base = __builtin_amdgcn_readlane(pre, done + m - 1);
