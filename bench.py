@@ -103,6 +103,9 @@ class Path:
         from objectdetection_amd.RPN.anchor_generator import AnchorGenerator
         from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
         self.ops = ops
+        # NMS launches bounded by what the finished steps needed (ops.NmsRounds: same keep lists; the first steps of a
+        # workload, before any has finished, enqueue every round)
+        self.nms_rounds = ops.NmsRounds()
         self.dev = dev
         self.ag = AnchorGenerator()
         self.pool = ROIPooling(['1'], [7, 7], 2)
@@ -142,7 +145,7 @@ class Path:
             mark("topk")
             boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
             mark("decode_clip_filter")
-        keep, n_keep = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
+        keep, n_keep = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS, rounds=self.nms_rounds)
         mark("nms")
         props = ops.gather_boxes(boxes, keep, n_keep)
         mark("gather")
@@ -170,7 +173,7 @@ class Path:
             mark("topk", pipe.s_prop)
             boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, IMG_H, IMG_W, MIN_SIZE)
             mark("decode_clip_filter", pipe.s_prop)
-            keep, n_keep = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
+            keep, n_keep = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS, rounds=self.nms_rounds)
             mark("nms", pipe.s_prop)
             props = ops.gather_boxes(boxes, keep, n_keep)
             mark("gather", pipe.s_prop)
@@ -867,17 +870,33 @@ def nms_microbench(path, dev):
         if n <= A:
             sets["bug_compatible"] = bug_compatible(n)
         for name, (boxes, count) in sets.items():
-            for _ in range(3):
-                keep, nk = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            reps = 10
-            for _ in range(reps):
-                keep, nk = ops.nms_sorted(boxes, count, NMS_THR, POST_NMS)
-            e1.record()
-            torch.cuda.synchronize()
-            res.setdefault("n%d" % n, {})[name] = {"ms_per_img": e0.elapsed_time(e1) / reps / B,
-                                                   "keeps_mean": float(nk.float().mean())}
+            def timed(fn, reps=10):
+                for _ in range(3):
+                    keep, nk = fn()
+                torch.cuda.synchronize()   # (the bounded form learns from calls that have finished)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    keep, nk = fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps / B, nk
+            every, nk = timed(lambda: ops.nms_sorted(boxes, count, NMS_THR, POST_NMS))
+            rr = ops.NmsRounds()
+            bounded, nk2 = timed(lambda: ops.nms_sorted(boxes, count, NMS_THR, POST_NMS, rounds=rr))
+            assert torch.equal(nk, nk2)
+            entry = {"ms_per_img": bounded, "ms_per_img_every_round": every, "keeps_mean": float(nk.float().mean()),
+                     "rounds_enqueued": rr.bound((dev.index, B, boxes.shape[1], POST_NMS, float(NMS_THR)), B)[0]}
+            if n == PRE_NMS and name == "realistic":
+                # the price of a wrong bound: one round enqueued, the tail launch finishes the batch alone
+                class OneRound(ops.NmsRounds):
+                    def bound(self, key, B_):
+                        return 1, self._slot(key, B_)
+                wr = OneRound()
+                entry["ms_per_img_bound_1_tail_works"], nk3 = timed(
+                    lambda: ops.nms_sorted(boxes, count, NMS_THR, POST_NMS, rounds=wr), reps=3)
+                assert torch.equal(nk, nk3)
+            res.setdefault("n%d" % n, {})[name] = entry
     out = {"nms_ms_per_img_batch16": res}
     out["nms_ms_per_img_n12000_batch16"] = res["n%d" % PRE_NMS]  # (the key round 1's line carried)
     return out

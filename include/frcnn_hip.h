@@ -144,6 +144,21 @@ int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, 
                          int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
                          void *stream);
 
+/* frcnn_nms_sorted_f32 with a bound on the launches (same call sites, RPN/rpn.py:84 / ROIHead/roi_head.py:215;
+ * the reference's per-image torchvision call has no such notion).  Above 2048 boxes NMS runs in rounds of 1024
+ * candidates, two launches per round; rounds after max_keep is reached exit at once but are still launched,
+ * because the host cannot know how many a batch needs (nine of twelve at 12,000 -> 2,000).  max_rounds > 0
+ * enqueues at most that many rounds and then ONE tail launch that finishes any image that is not done, one
+ * workgroup per image: slow when it has to work, and exact -- keep lists never depend on max_rounds
+ * (max_rounds <= 0, or min(max_keep, max_n) > 2048: every round, no tail).  rounds_used: (B) int32, device or
+ * host-mapped (pinned) memory, or NULL; written once, by the call's last launch: per image the rounds that had
+ * work to do, or the total number of rounds for an image the tail had to finish.  A caller feeds
+ * max(rounds_used) + 1 of one batch to the next call (objectdetection_amd.ops.NmsRounds). */
+int frcnn_nms_sorted_rounds_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
+                                double iou_threshold, int max_keep, int32_t *keep_out,
+                                int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
+                                int max_rounds, int32_t *rounds_used, void *stream);
+
 /* frcnn_nms_sorted_f32 for callers that cannot allocate device memory.  NO COUNTERPART IN THE REFERENCE: it
  * exists for callers under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same
  * arguments, kernels and results, but the round path's workspace is a file-scope device array inside the

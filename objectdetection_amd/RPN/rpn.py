@@ -24,6 +24,8 @@ class RPN(Module):
         self.num_pre_nms = dict_params['num_pre_nms']
         self.num_post_nms = dict_params['num_post_nms']
         self.nms_threshold = dict_params['nms_threshold']
+        # launches of the round-path NMS bounded by what the previous batches needed (same keep lists)
+        self.nms_rounds = ops.NmsRounds()
         self.proposal_min_size = dict_params['proposal_min_size']
         self.pos_threshold = dict_params['pos_threshold']
         self.neg_threshold = dict_params['neg_threshold']
@@ -61,7 +63,8 @@ class RPN(Module):
             top_val, top_idx = ops.topk_desc(scores, k, max_slices=self.topk_max_slices)   # rpn.py:66-67
             boxes, _, _, count = ops.decode_clip_filter(                       # rpn.py:68-69,75,81-83
                 anchors, deltas, top_idx, top_val, info[1], info[2], self.proposal_min_size)
-        keep, n_keep = ops.nms_sorted(boxes, count, self.nms_threshold, self.num_post_nms)  # rpn.py:84
+        keep, n_keep = ops.nms_sorted(boxes, count, self.nms_threshold, self.num_post_nms,  # rpn.py:84
+                                      rounds=self.nms_rounds)
         props = ops.gather_boxes(boxes, keep, n_keep)                          # rpn.py:85
         return props, n_keep
 

@@ -39,6 +39,7 @@ SIGNATURES = {
                                                _P]),
     "frcnn_nms_workspace_bytes": (_Z, [_I, _I]),
     "frcnn_nms_sorted_f32": (_I, [_P, _P, _I, _I, _D, _I, _P, _P, _P, _Z, _P]),
+    "frcnn_nms_sorted_rounds_f32": (_I, [_P, _P, _I, _I, _D, _I, _P, _P, _P, _Z, _I, _P, _P]),
     "frcnn_nms_static_scratch_bytes": (_Z, []),
     "frcnn_nms_sorted_static_f32": (_I, [_P, _P, _I, _I, _D, _I, _P, _P, _P]),
     "frcnn_gather_boxes_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),

@@ -56,6 +56,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 // instead of n^2/2 = 72 M at n = 12,000).  Same fp32 IoU expression, same threshold rule.
 #define NMS_LAZY_THREADS 1024
 #define NMS_LAZY_WAVES 16
+#define NMS_RT_BYTES (136 * 64 * 8) // one round's tiles in the round path's workspace (NMS_RT * 64 words, below)
 
 __device__ __forceinline__ float lane_bcast(float v, int src_lane)
 {
@@ -65,7 +66,8 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane)
 __global__ void __launch_bounds__(NMS_LAZY_THREADS)
 nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image, int max_n,
                 FrcnnThr thr, int max_keep, int cap, int32_t *__restrict__ keep_out,
-                int32_t *__restrict__ n_keep_out)
+                int32_t *__restrict__ n_keep_out, int first_block, const char *resume_ws, size_t resume_stride,
+                int resume_cap, int total_rounds, int32_t *rounds_used)
 {
     // dynamic LDS: [cap] kept boxes (float4), [cap] kept areas, [cap] kept positions
     extern __shared__ float4 s_kbox[];
@@ -81,13 +83,35 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const float4 *bx = boxes + (long long)b * max_n;
+    // Resume form (the round path's tail, see nms_sorted_run): the image's state is what the rounds before
+    // `first_block` left in the workspace.  Nothing to do -- the normal case -- when they reached max_keep or the
+    // end of the candidates; otherwise the kept list is fetched into LDS and the candidates from first_block on
+    // are worked off here, one workgroup per image (slow next to the rounds, and exact all the same).
+    int nk0 = 0;
+    if (resume_ws) {
+        const char *p = resume_ws + (size_t)b * resume_stride;
+        const float4 *kbox = (const float4 *)p;
+        p += ((size_t)resume_cap * 16 + 255) / 256 * 256;
+        const float *karea = (const float *)p;
+        p += ((size_t)resume_cap * 4 + 255) / 256 * 256 + (size_t)NMS_RT_BYTES + 256;
+        const int *state = (const int *)p; // nkeep, dense, rounds
+        nk0 = state[0];
+        const bool idle = first_block * 64 >= n || nk0 >= max_keep;
+        if (threadIdx.x == 0 && rounds_used) rounds_used[b] = idle ? state[2] : total_rounds;
+        if (idle) return;
+        for (int t = threadIdx.x; t < nk0; t += NMS_LAZY_THREADS) {
+            s_kbox[t] = kbox[t];
+            s_karea[t] = karea[t];
+        }
+    }
     if (threadIdx.x == 0) {
-        s_nkeep = 0;
+        s_nkeep = nk0;
         s_rem[0] = 0;
         s_rem[1] = 0;
     }
-    int nkeep_final = 0;
-    for (int c0 = 0; c0 < Wn; c0 += NMS_LAZY_WAVES) {
+    __syncthreads();
+    int nkeep_final = nk0;
+    for (int c0 = first_block; c0 < Wn; c0 += NMS_LAZY_WAVES) {
         // refill: one coalesced 16-KB read serves the next 16 candidate blocks; no global memory
         // operation is issued inside the per-block loop below, so its barriers are cheap
         {
@@ -180,7 +204,7 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
     __syncthreads();
     nkeep_final = s_nkeep;
     int32_t *keep = keep_out + (long long)b * max_keep;
-    for (int t = threadIdx.x; t < nkeep_final; t += NMS_LAZY_THREADS) keep[t] = s_kidx[t];
+    for (int t = nk0 + threadIdx.x; t < nkeep_final; t += NMS_LAZY_THREADS) keep[t] = s_kidx[t];
     if (threadIdx.x == 0) n_keep_out[b] = nkeep_final;
 }
 
@@ -193,6 +217,7 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
 #endif
 #define NMS_DENSE 512                     // survivors per round from which chip-wide tiles pay off
 #define NMS_TILE_WORDS ((NMS_RT * 64 + 1023) / 1024) // tile words per thread of the scan kernel (9)
+static_assert(NMS_RT_BYTES == NMS_RT * 64 * 8, "NMS_RT_BYTES");
 #define NMS_TILE_GROUPS ((NMS_RT + NMS_RC * 4 - 1) / (NMS_RC * 4)) // grid.y slices of tile waves (3)
 
 // Per-image workspace of the round path (all offsets 16-byte aligned).
@@ -203,6 +228,7 @@ struct NmsWs {
     unsigned long long *sup;   // [NMS_RC] this round's pull result (zero between rounds)
     int *nkeep;                // [1]
     int *dense;                // [1] last round left >= NMS_DENSE survivors of the pull: precompute tiles
+    int *rounds;               // [1] rounds that had work to do so far
 };
 
 static size_t nms_ws_stride(int cap)
@@ -225,6 +251,7 @@ __device__ __forceinline__ NmsWs nms_ws(char *base, size_t stride, int b, int ca
     p += 256;
     w.nkeep = (int *)p;
     w.dense = w.nkeep + 1;
+    w.rounds = w.nkeep + 2;
     return w;
 }
 
@@ -400,7 +427,7 @@ __global__ void __launch_bounds__(1024)
 nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
                       int max_n, FrcnnThr thr, int max_keep, int cap, int round, char *ws,
                       size_t ws_stride, int32_t *__restrict__ keep_out,
-                      int32_t *__restrict__ n_keep_out)
+                      int32_t *__restrict__ n_keep_out, int32_t *rounds_used)
 {
     __shared__ unsigned long long s_tiles[NMS_RT * 64];
     __shared__ float4 s_box[NMS_RS];   // the list's boxes
@@ -419,7 +446,11 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     if (base >= n || nk0 >= max_keep) {
         if (threadIdx.x == 0) {
             n_keep_out[b] = nk0;
-            if (round == 0) *w.nkeep = 0; // (an empty image: what the later rounds report)
+            if (round == 0) {
+                *w.nkeep = 0; // (an empty image: what the later rounds report)
+                *w.rounds = 0;
+            }
+            if (rounds_used) rounds_used[b] = round == 0 ? 0 : *w.rounds; // (the call's last round publishes)
         }
         return;
     }
@@ -559,7 +590,9 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     if (t == 0) {
         *w.nkeep = s_nkeep;
         *w.dense = dense ? 1 : 0;
+        *w.rounds = round + 1;
         n_keep_out[b] = s_nkeep;
+        if (rounds_used) rounds_used[b] = round + 1;
     }
 }
 
@@ -582,9 +615,16 @@ static FrcnnThr make_threshold(double thr)
     return th;
 }
 
+// max_rounds > 0: enqueue at most that many rounds of the round path, then ONE tail launch that finishes whatever
+// image is not done (nms_lazy_kernel's resume form) -- for callers who know from the previous batch how many rounds
+// do any work: rounds after max_keep is reached exit at once, but still cost two launches each (nine of twelve at
+// 12,000 -> 2,000).  The result never depends on max_rounds.  rounds_used (B ints, may be host-mapped memory, may
+// be null): per image, the rounds that had work -- written once, by the call's last launch; the total round count
+// for an image that the tail had to finish.
 static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B, int max_n,
                           double iou_threshold, int max_keep, int32_t *keep_out, int32_t *n_keep_out,
-                          void *workspace, size_t workspace_bytes, void *stream)
+                          void *workspace, size_t workspace_bytes, int max_rounds, int32_t *rounds_used,
+                          void *stream)
 {
     FRCNN_REQUIRE(B >= 0 && max_n >= 0 && max_keep >= 0, "nms: bad shape");
     if (B == 0) return FRCNN_OK;
@@ -610,7 +650,7 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
         }
         hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
                            (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out,
-                           n_keep_out);
+                           n_keep_out, 0, (const char *)nullptr, (size_t)0, 0, 0, (int32_t *)nullptr);
         FRCNN_CHECK_LAUNCH("nms_lazy");
         return FRCNN_OK;
     }
@@ -627,15 +667,30 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
     int rsplit = (NMS_PULL_WGS + NMS_RC * B - 1) / (NMS_RC * B); // pull slices: ~NMS_PULL_WGS workgroups in flight
     if (rsplit < 1) rsplit = 1;
     if (rsplit > 16) rsplit = 16;
-    for (int r = 0; r < rounds; ++r) {
+    // the tail keeps its kept list in LDS: only when that fits (RPN: 2,000 keeps) can rounds be left out
+    int run = rounds;
+    if (max_rounds > 0 && max_rounds < rounds && cap <= NMS_LAZY_MAX_N) run = max_rounds;
+    for (int r = 0; r < run; ++r) {
         hipLaunchKernelGGL(nms_round_pm_kernel, dim3(NMS_RC, rsplit + NMS_TILE_GROUPS, B), dim3(256), 0, st,
                            (const float4 *)boxes, n_per_image, max_n, thr, max_keep, max_n, r, rsplit,
                            (char *)workspace, stride);
         FRCNN_CHECK_LAUNCH("nms_round_pm");
         hipLaunchKernelGGL(nms_round_scan_kernel, dim3(B), dim3(1024), 0, st, (const float4 *)boxes,
                            n_per_image, max_n, thr, max_keep, max_n, r, (char *)workspace, stride,
-                           keep_out, n_keep_out);
+                           keep_out, n_keep_out, (run == rounds && r == rounds - 1) ? rounds_used : (int32_t *)nullptr);
         FRCNN_CHECK_LAUNCH("nms_round_scan");
+    }
+    if (run < rounds) {
+        const size_t lazy_lds = (size_t)cap * 24;
+        if (lazy_lds > 48 * 1024) {
+            static size_t granted[FRCNN_MAX_DEVICES];
+            hipError_t e = frcnn_reserve_dynamic_lds((const void *)nms_lazy_kernel, NMS_LAZY_MAX_N * 24, granted);
+            FRCNN_REQUIRE(e == hipSuccess, "nms: cannot reserve LDS: %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
+                           (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out, n_keep_out,
+                           run * NMS_RC, (const char *)workspace, stride, max_n, rounds, rounds_used);
+        FRCNN_CHECK_LAUNCH("nms_tail");
     }
     return FRCNN_OK;
 }
@@ -646,7 +701,16 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
                                     void *stream)
 {
     return nms_sorted_run(boxes, n_per_image, B, max_n, iou_threshold, max_keep, keep_out, n_keep_out, workspace,
-                          workspace_bytes, stream);
+                          workspace_bytes, 0, nullptr, stream);
+}
+
+extern "C" int frcnn_nms_sorted_rounds_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
+                                           double iou_threshold, int max_keep, int32_t *keep_out,
+                                           int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
+                                           int max_rounds, int32_t *rounds_used, void *stream)
+{
+    return nms_sorted_run(boxes, n_per_image, B, max_n, iou_threshold, max_keep, keep_out, n_keep_out, workspace,
+                          workspace_bytes, max_rounds, rounds_used, stream);
 }
 
 // ---- the entry point that allocates nothing ---------------------------------------------------------
@@ -700,5 +764,5 @@ extern "C" int frcnn_nms_sorted_static_f32(const float *boxes, const int32_t *n_
         if (rc != FRCNN_OK) return rc;
     }
     return nms_sorted_run(boxes, n_per_image, B, max_n, iou_threshold, max_keep, keep_out, n_keep_out, ws, need,
-                          stream);
+                          0, nullptr, stream);
 }

@@ -462,9 +462,38 @@ def decode_clip_filter(anchors, deltas, top_idx, top_score, image_h, image_w, mi
 
 
 # --------------------------------------------------------------------------------------- K4 NMS
-def nms_sorted(boxes, n_per_image, iou_threshold, max_keep):
+class NmsRounds:
+    """How many rounds of the round-path NMS the caller's recent batches needed, fed forward as the next call's
+    launch bound (frcnn_nms_sorted_rounds_f32).  The kernels leave the per-image round counts of a call in pinned
+    host memory that the GPU writes directly; the host reads whatever has landed -- the counts of the last call
+    that FINISHED, never a synchronisation -- and asks for one round more than their maximum.  Until a first
+    call has finished (or after a batch that needed its tail launch) every round is enqueued, as without it.
+    Keep lists do not depend on the bound; one object per call site and stream."""
+
+    UNKNOWN = 1 << 20
+
+    def __init__(self, margin=1):
+        self.margin = int(margin)
+        self._used = {}
+
+    def _slot(self, key, B):
+        t = self._used.get(key)
+        if t is None:
+            t = torch.full((B,), self.UNKNOWN, dtype=torch.int32).pin_memory()
+            self._used[key] = t
+        return t
+
+    def bound(self, key, B):
+        """-> (max_rounds argument, pinned tensor the call reports into)."""
+        t = self._slot(key, B)
+        m = int(t.max())
+        return (0 if m >= self.UNKNOWN else m + self.margin), t
+
+
+def nms_sorted(boxes, n_per_image, iou_threshold, max_keep, rounds=None):
     """Batched greedy NMS over rows already in descending-score order.
-    boxes (B,n,4); n_per_image (B) int32 device or None.  -> keep (B,max_keep) int32, n_keep (B)."""
+    boxes (B,n,4); n_per_image (B) int32 device or None.  -> keep (B,max_keep) int32, n_keep (B).
+    rounds: an NmsRounds that bounds the launches by what earlier batches needed (same result), or None."""
     _need_gpu(boxes, n_per_image)
     boxes = _f32c(boxes)
     B, n = boxes.shape[0], boxes.shape[1]
@@ -478,8 +507,14 @@ def nms_sorted(boxes, n_per_image, iou_threshold, max_keep):
     if n_per_image is not None and n_per_image.dtype != torch.int32:
         n_per_image = n_per_image.to(torch.int32)
     with torch.cuda.device(dev):
-        rc = lib.frcnn_nms_sorted_f32(_ptr(boxes), _ptr(n_per_image), B, n, float(iou_threshold), max_keep,
-                                      _ptr(keep), _ptr(n_keep), _ptr(ws), nbytes, _stream())
+        if rounds is not None and nbytes > 0 and B > 0:
+            max_rounds, used = rounds.bound((dev.index, B, n, max_keep, float(iou_threshold)), B)
+            rc = lib.frcnn_nms_sorted_rounds_f32(_ptr(boxes), _ptr(n_per_image), B, n, float(iou_threshold), max_keep,
+                                                 _ptr(keep), _ptr(n_keep), _ptr(ws), nbytes, max_rounds,
+                                                 used.data_ptr(), _stream())
+        else:
+            rc = lib.frcnn_nms_sorted_f32(_ptr(boxes), _ptr(n_per_image), B, n, float(iou_threshold), max_keep,
+                                          _ptr(keep), _ptr(n_keep), _ptr(ws), nbytes, _stream())
     _lib.check(rc, "nms_sorted")
     return keep[:, :max_keep], n_keep
 

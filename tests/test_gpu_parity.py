@@ -805,6 +805,77 @@ def test_nms_workspace_needs_no_clearing(dev, oracle):
         assert np.array_equal(keep[i, :nk[i]].cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("max_rounds", [1, 2, 3, 5, 0])
+def test_nms_round_bound_never_changes_the_result(dev, oracle, max_rounds):
+    """frcnn_nms_sorted_rounds_f32 through the C ABI: with fewer rounds enqueued than the batch needs, the tail
+    launch finishes the images that are not done and the keep lists are those of the unbounded call (and of the
+    oracle).  Images: empty, one round, max_keep reached in round 2, all 6 rounds needed (sparse boxes, few keeps),
+    ragged.  rounds_used (pinned host memory the kernels write directly) = rounds that had work, or all of them
+    for an image the tail had to finish."""
+    from objectdetection_amd import _lib
+    rng = np.random.default_rng(77)
+    n, P = 6000, 900
+    ns = [0, 700, 6000, 6000, 3500]
+    boxes = np.stack([realistic_boxes(rng, n, 1000, 600) for _ in ns])
+    # image 3: heavy overlap -> few keeps, every round has work
+    c = rng.uniform(100, 140, (n, 2)).astype(np.float32)
+    wh = rng.uniform(150, 170, (n, 2)).astype(np.float32)
+    boxes[3] = np.concatenate([c, c + wh], 1)
+    B = len(ns)
+    bx = T(boxes, dev)
+    cnt = T(np.asarray(ns, np.int32), dev, torch.int32)
+    lib = _lib.load()
+    nbytes = lib.frcnn_nms_workspace_bytes(B, n)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(bound):
+        ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=dev)
+        keep = torch.full((B, P), -7, dtype=torch.int32, device=dev)
+        n_keep = torch.full((B,), -7, dtype=torch.int32, device=dev)
+        used = torch.full((B,), -7, dtype=torch.int32).pin_memory()
+        rc = lib.frcnn_nms_sorted_rounds_f32(bx.data_ptr(), cnt.data_ptr(), B, n, 0.7, P, keep.data_ptr(),
+                                             n_keep.data_ptr(), ws.data_ptr(), nbytes, bound, used.data_ptr(), st)
+        assert rc == 0, lib.frcnn_last_error_string()
+        torch.cuda.synchronize()
+        return keep.cpu().numpy(), n_keep.cpu().numpy(), used.numpy().copy()
+
+    keep, nk, used = run(max_rounds)
+    keep0, nk0, used0 = run(0)
+    assert np.array_equal(nk, nk0) and np.array_equal(keep, keep0)
+    for i, m in enumerate(ns):
+        ref = oracle.nms(boxes[i, :m], np.arange(m, 0, -1, dtype=np.float32), 0.7)[:P] if m else np.zeros((0,), np.int64)
+        assert nk[i] == len(ref), (i, nk[i], len(ref))
+        assert np.array_equal(keep[i, :nk[i]], ref)
+    total = (n + 1023) // 1024
+    assert used0[0] == 0 and used0[1] == 1 and used0[3] == total and 1 <= used0[2] < total and used0[4] <= 4
+    bound = max_rounds if max_rounds > 0 else total
+    for i in range(B):   # done within the bound: the true count; else the tail worked: all rounds
+        assert used[i] == (used0[i] if used0[i] <= bound else total), (i, used, used0)
+
+
+def test_nms_rounds_feed_forward(dev):
+    """ops.nms_sorted(rounds=NmsRounds()): the first call enqueues every round, later calls one more than the
+    finished calls needed; results identical, and a batch that needs more than the bound still comes out right."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(78)
+    B, n, P = 3, 5000, 400
+    easy = T(np.stack([realistic_boxes(rng, n, 1000, 600) for _ in range(B)]), dev)
+    c = rng.uniform(100, 140, (B, n, 2)).astype(np.float32)
+    hard = T(np.concatenate([c, c + rng.uniform(150, 170, (B, n, 2)).astype(np.float32)], 2), dev)
+    ref_easy = ops.nms_sorted(easy, None, 0.7, P)
+    ref_hard = ops.nms_sorted(hard, None, 0.7, P)
+    r = ops.NmsRounds()
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), B, n, P, 0.7)
+    assert r.bound(key, B)[0] == 0                      # nothing known: every round
+    for expect_ref, boxes in ((ref_easy, easy), (ref_easy, easy), (ref_hard, hard), (ref_hard, hard), (ref_easy, easy)):
+        keep, nk = ops.nms_sorted(boxes, None, 0.7, P, rounds=r)
+        torch.cuda.synchronize()
+        assert torch.equal(nk, expect_ref[1])
+        for b in range(B):
+            assert torch.equal(keep[b, :int(nk[b])], expect_ref[0][b, :int(nk[b])])
+    assert 1 <= r.bound(key, B)[0] <= 5                 # after an easy batch: its rounds + 1
+
+
 def test_roi_pool_max_vs_oracle(dev, oracle):
     from objectdetection_amd import ops
     rng = np.random.default_rng(11)
