@@ -104,18 +104,19 @@ __device__ __forceinline__ void rab_wait(RabG &g)
 // D[row][x] = sum_ph Wy[ph][row] T[ph][x] as four rows rb + 4 q + v per lane, added to the cells; rows / columns
 // outside the footprint go to a dummy cell.
 __device__ __forceinline__ void rab_scatter(const RabG &g, const RabLane &L, const float *s_tab, int e_off, int e_ymin,
-                                            int e_ny, int e_xmin, int e_nx, int W, int q, int li, int lane_rel, f32x2 *plane,
-                                            f32x2 *dummy)
+                                            int e_ny, int e_xmin, int e_nx, int W, int q, int li, char *lds,
+                                            const unsigned (&cell_v)[4], unsigned dummy)
 {
+    // cell_v[v] = byte offset in LDS of this lane's cell of row 4 q + v, column li of the wave's planes; the block's
+    // origin is a scalar on top.  Rows the lane owns in a block: v < nrow.
     const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x2 *const lane_cell = plane + lane_rel; // lane_rel = 4 q W + li
     const float glo = L.ok_lo ? g.lo : 0.0f, ghi = L.ok_hi ? g.hi : 0.0f;
     for (int xb = 0; xb < e_nx; xb += 16) {
         const int xc = xb + li;
         const float *wp = s_tab + (e_off + e_ny + min(xc, e_nx - 1)) * 8 + q;
         f32x4 t = __builtin_amdgcn_mfma_f32_16x16x4f32(glo, wp[0], z, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x4f32(ghi, wp[4], t, 0, 0, 0);
-        const bool col_ok = xc < e_nx;
+        const int rows_here = xc < e_nx ? e_ny - 4 * q : 0;
         for (int rb = 0; rb < e_ny; rb += 16) {
             const float *ap = s_tab + (e_off + min(rb + li, e_ny - 1)) * 8 + q;
             const float alo = ap[0], ahi = ap[4];
@@ -123,17 +124,17 @@ __device__ __forceinline__ void rab_scatter(const RabG &g, const RabLane &L, con
             f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t.z, z, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t.y, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t.w, acc1, 0, 0, 0);
-            const int row0 = rb + 4 * q;
-            f32x2 *cell = lane_cell + ((e_ymin + rb) * W + e_xmin + xb);
-            f32x2 *p0 = col_ok && row0 + 0 < e_ny ? cell : dummy;
-            f32x2 *p1 = col_ok && row0 + 1 < e_ny ? cell + W : dummy;
-            f32x2 *p2 = col_ok && row0 + 2 < e_ny ? cell + 2 * W : dummy;
-            f32x2 *p3 = col_ok && row0 + 3 < e_ny ? cell + 3 * W : dummy;
+            const int nrow = rows_here - rb;
+            const unsigned origin = (unsigned)(((e_ymin + rb) * W + e_xmin + xb) * 8);
+            f32x2 *p0 = (f32x2 *)(lds + (0 < nrow ? cell_v[0] + origin : dummy));
+            f32x2 *p1 = (f32x2 *)(lds + (1 < nrow ? cell_v[1] + origin : dummy));
+            f32x2 *p2 = (f32x2 *)(lds + (2 < nrow ? cell_v[2] + origin : dummy));
+            f32x2 *p3 = (f32x2 *)(lds + (3 < nrow ? cell_v[3] + origin : dummy));
             const f32x2 o0 = *p0, o1 = *p1, o2 = *p2, o3 = *p3;
-            *p0 = o0 + (f32x2){acc0.x, acc1.x};
-            *p1 = o1 + (f32x2){acc0.y, acc1.y};
-            *p2 = o2 + (f32x2){acc0.z, acc1.z};
-            *p3 = o3 + (f32x2){acc0.w, acc1.w};
+            *p0 = (f32x2){o0.x + acc0.x, o0.y + acc1.x};
+            *p1 = (f32x2){o1.x + acc0.y, o1.y + acc1.y};
+            *p2 = (f32x2){o2.x + acc0.z, o2.y + acc1.z};
+            *p3 = (f32x2){o3.x + acc0.w, o3.y + acc1.w};
         }
     }
 }
@@ -190,14 +191,16 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
     const int per = (cnt + splits - 1) / splits;
     const int j_end = min(cnt, (split + 1) * per);
     const float4 *pb = props + (long long)b * P;
-    f32x2 *const plane = s_pl + wave * HW;
     const int ch0 = c0 + 2 * wave;
     const bool has0 = ch0 < C, has1 = ch0 + 1 < C;
     const float *gb = grad_out + ((long long)s_off * C + min(ch0, C - 1)) * 49;
     const int q = lane >> 4, li = lane & 15;
-    const int lane_rel = 4 * q * W + li;
     const RabLane GL = rab_lane(lane, has1 ? 49 : 0);
-    f32x2 *const dummy = s_dummy + lane;
+    char *const lds = (char *)s_dyn;
+    const unsigned dummy = (unsigned)((char *)(s_dummy + lane) - lds);
+    unsigned cell_v[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) cell_v[v] = (unsigned)((wave * HW + (4 * q + v) * W + li) * 8);
     for (int jw = split * per; jw < j_end; jw += 64) {
         // ---- lane = candidate RoI jw + lane: footprint and table size (every wave computes the same values)
         bool live = jw + lane < j_end;
@@ -289,7 +292,7 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
                             const int e_ymin = __builtin_amdgcn_readlane(ymin, e), e_ny = __builtin_amdgcn_readlane(ny, e);
                             const int e_xmin = __builtin_amdgcn_readlane(xmin, e), e_nx = __builtin_amdgcn_readlane(nx, e);
                             rab_wait(G[d]);
-                            rab_scatter(G[d], GL, s_tab, e_off, e_ymin, e_ny, e_xmin, e_nx, W, q, li, lane_rel, plane, dummy);
+                            rab_scatter(G[d], GL, s_tab, e_off, e_ymin, e_ny, e_xmin, e_nx, W, q, li, lds, cell_v, dummy);
                             E[d] = next();
                             rab_load(G[d], gb, jw + (E[d] >= 0 ? E[d] : e_first), C, GL);
                         }
