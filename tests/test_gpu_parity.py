@@ -1564,6 +1564,35 @@ def test_roi_align_backward_adjoint_of_closed_form(dev):
         np.testing.assert_allclose(rhs, lhs, rtol=1e-5, atol=1e-3)
 
 
+def test_roi_align_backward_full_batch_adjoint_and_determinism(dev):
+    """Batch 16 x 2,000 RoIs on the headline map (256 channels = 256 workgroups: one per (image, chunk), no RoI split,
+    ~90 table batches each).
+    <RoIAlign(f), G> = <f, RoIAlign^T(G)> per (image, channel) against the forward plane kernel (whose values the
+    oracle and the closed forms pin), and the same bits run to run (no atomics on this form)."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(17)
+    B, P, C, H, W = 16, 2000, 256, 37, 62
+    props = T(np.stack([realistic_boxes(rng, P, 1000, 600) for _ in range(B)]), dev)
+    cnt = T(rng.integers(1500, P + 1, B).astype(np.int32), dev, torch.int32)
+    cfg = ((7, 7), 2, (1.0 / 16,), 4, 4)
+    torch.manual_seed(3)
+    f = torch.randn((B, C, H, W), device=dev)
+    y, total = ops._roi_align_levels(cfg, props, cnt, [f])
+    K = int(total)
+    assert K == int(cnt.sum())
+    G = torch.randn((K, C, 7, 7), device=dev)
+    g1 = ops.roi_align_levels_backward(cfg, props, cnt, G, [(B, C, H, W)])[0]
+    g2 = ops.roi_align_levels_backward(cfg, props, cnt, G, [(B, C, H, W)])[0]
+    assert torch.equal(g1, g2)
+    img = torch.repeat_interleave(torch.arange(B, device=dev), cnt.long())
+    terms = (y[:K].double() * G.double()).sum(dim=(2, 3))
+    lhs = torch.zeros((B, C), dtype=torch.float64, device=dev).index_add_(0, img, terms)
+    scale = torch.zeros((B, C), dtype=torch.float64, device=dev).index_add_(
+        0, img, (y[:K].double().abs() * G.double().abs()).sum(dim=(2, 3)))
+    rhs = (f.double() * g1.double()).sum(dim=(2, 3))
+    assert float(((lhs - rhs).abs() / scale).max()) < 1e-6
+
+
 def test_roi_head_training_sends_gradients_to_the_feature_maps(dev):
     """ROIHead(force_eval=False).train(): the RoI losses reach the feature maps through the pooling, as they do in the
     reference (torchvision's op is differentiable); under no_grad / for maps that need none, nothing is recorded."""
