@@ -474,6 +474,7 @@ def main():
         extras.update(targets_microbench(path, dev))
         extras.update(roi_pool_microbench(path, dev))
         extras.update(config5_microbench(dev))
+        extras.update(config5_microbench(dev, B=8, reps=3, levels=5))   # SURVEY's extra stress point, A = 805,707
         c64 = config5_microbench(dev, B=64, reps=3)   # BASELINE configs[4] names batch 64
         extras["config5_A200907_k30000_C256_batch64"] = c64["config5_A200907_k30000_C256"]
         extras.update(hbm_probe(dev))
@@ -703,12 +704,13 @@ def targets_microbench(path, dev):
     return {"training_targets_config3": res}
 
 
-def config5_inputs(B, dev, seed=7):
+def config5_inputs(B, dev, seed=7, levels=4):
     """800x1344, levels 13x21 .. 100x168 (A = 200,907), C = 256, tie-free logits,
-    proposal-realistic deltas under the reference decode."""
+    proposal-realistic deltas under the reference decode.  levels=5 adds P2 (200x336): A = 805,707, SURVEY's
+    extra stress point."""
     from objectdetection_amd.RPN.anchor_generator import AnchorGenerator
     Himg, Wimg, C5 = 800, 1344, 256
-    fsz = [(13, 21), (25, 42), (50, 84), (100, 168)]
+    fsz = [(13, 21), (25, 42), (50, 84), (100, 168), (200, 336)][:levels]
     g = torch.Generator().manual_seed(seed)
     A5 = sum(h * w for h, w in fsz) * NA
     perm = (torch.stack([torch.randperm(A5, generator=g) for _ in range(B)]).float() / A5 - 0.5) * 8
@@ -735,13 +737,13 @@ def config5_inputs(B, dev, seed=7):
     return dict(cls=cls, reg=reg, feats=feats, anchors=anchors, Himg=Himg, Wimg=Wimg, A=A5, C=C5, fsz=fsz)
 
 
-def config5_microbench(dev, B=16, reps=5):
+def config5_microbench(dev, B=16, reps=5, levels=4):
     """The whole path at SURVEY 8d config 5 (k = 30,000, P = 2,000, four-level MultiScaleRoIAlign), one
-    stream; a parity-test configuration reported beside the headline, not the metric."""
+    stream; a parity-test configuration reported beside the headline, not the metric.  levels=5: with P2."""
     from objectdetection_amd import ops
     from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
-    x = config5_inputs(B, dev)
-    pool = ROIPooling(['1', '2', '3', '4'], [7, 7], 2)
+    x = config5_inputs(B, dev, levels=levels)
+    pool = ROIPooling([str(i + 1) for i in range(levels)], [7, 7], 2)
     fd = {str(i + 1): f for i, f in enumerate(x["feats"][::-1])}  # fine to coarse
     rounds = ops.NmsRounds()  # (as the RPN module does: 30 rounds of which the first few work)
 
@@ -784,7 +786,7 @@ def config5_microbench(dev, B=16, reps=5):
     stage = {k: float(np.mean(v)) for k, v in acc.items()}
     ms = sum(stage.values())
     out_bytes = int(total) * x["C"] * 49 * 4
-    return {"config5_A200907_k30000_C256": {
+    return {"config5_A%d_k30000_C256" % x["A"]: {
         "batch": B, "ms_per_step": ms, "images_per_s": B / (ms * 1e-3), "stage_ms": stage,
         "rois_per_step": int(total), "keeps_per_img_mean": float(nk.float().mean()),
         "roi_align_write_GBps": out_bytes / (stage["roi_align"] * 1e-3) / 1e9,
