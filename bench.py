@@ -469,6 +469,13 @@ def main():
         key = "two_batches_in_flight" if args.serial else "serial"
         extras[key] = {k: oth[k] for k in ("value", "ms_per_step", "stage_ms")}
         extras[key]["roofline_frac"] = oth["roofline"]["frac"]
+        # BASELINE configs[3] (batch 256 over 8 GPUs): one rank's share, 32 images per step, on this GPU
+        if B != 32:
+            r32, _, _ = run_workload(path, dev, None, 0, 1, 32, args.workload, max(5, args.steps // 5), 2, pipelined=False)
+            extras["configs3_rank_share_batch32"] = {k: r32[k] for k in ("value", "ms_per_step", "stage_ms")}
+            extras["configs3_rank_share_batch32"]["roofline_frac"] = r32["roofline"]["frac"]
+            del r32
+            torch.cuda.empty_cache()
         extras.update(nms_microbench(path, dev))
         extras.update(next_rows_microbench(dev))
         extras.update(targets_microbench(path, dev))
