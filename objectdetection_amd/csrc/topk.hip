@@ -558,11 +558,20 @@ __device__ __forceinline__ unsigned long long wave_match11(unsigned digit, bool 
 struct FlatScores {
     const float *sc;
     __device__ __forceinline__ uint32_t key(int e) const { return frcnn_score_key(sc[e]); }
+    __device__ __forceinline__ unsigned idx(int e) const { return (unsigned)e; }
 };
 
 struct ReadyKeys {
     const uint32_t *keys;
     __device__ __forceinline__ uint32_t key(int e) const { return keys[e]; }
+    __device__ __forceinline__ unsigned idx(int e) const { return (unsigned)e; }
+};
+
+// keys that survived a filter, in index order, with the place each one came from (< 2^15)
+struct CompactKeys {
+    const uint32_t *keys, *orig;
+    __device__ __forceinline__ uint32_t key(int e) const { return keys[e]; }
+    __device__ __forceinline__ unsigned idx(int e) const { return orig[e]; }
 };
 
 template <int KR, bool RAWKEY, typename Src>
@@ -596,7 +605,7 @@ __device__ __forceinline__ void topk_sort_body(const Src src, int n, int k, uint
             const bool act = e < seg_hi;
             if (pass == 0) {
                 kreg[r] = act ? src.key(e) : 0u;
-                ireg[r] = (unsigned)e;
+                ireg[r] = act ? src.idx(e) : 0u;
             } else {
                 kreg[r] = act ? kin[e] : 0u;
                 ireg[r] = act ? iin[e] : 0u;
@@ -742,6 +751,144 @@ topk_slice_sort_nchw_kernel(RpnLevels L, int n, int k, int S, int slice_len, int
     topk_sort_body<KR, true>(src, n_s, min(k, n_s), skeys + list, sidx + list, wss);
 }
 
+// ---- selective variant: k is a small part of n (FPN: 30,000 of 200,907 or of 805,707) --------------------
+// Sorting every slice in full is then mostly wasted: a slice's sort costs ~10 us per 1,000 scores, and the merge
+// looks at every listed element.  Three cheap steps first decide which scores can matter at all:
+//   topk_slice_hist_kernel: every slice makes its keys (kept for the sort) and a 4096-bin histogram of their
+//                           top 12 bits, written to its own row of the workspace (no atomics, nothing to clear);
+//   topk_pick_kernel:       per image, the bin in which the k-th largest key lies -> threshold T = that bin's
+//                           lowest key: at least k keys are >= T, and every key of the top k is;
+//   topk_slice_sort_sel_kernel: a slice compacts its keys >= T in place (index order, so ties keep their rule),
+//                           sorts only those, and records how many it listed for the merge.
+// Nothing is approximate: the merge ranks exactly as before over shorter lists, and a degenerate input (all
+// scores in one bin) just falls back to sorting everything, at the old cost.
+#define TOPK_SEL_BITS 12
+#define TOPK_SEL_BINS (1 << TOPK_SEL_BITS)
+
+template <bool NCHW>
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_slice_hist_kernel(const float *__restrict__ scores, RpnLevels L, int n, int S, int slice_len,
+                       uint32_t *__restrict__ ws, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned s_hist[TOPK_SEL_BINS];
+    const long long b = blockIdx.x / S;
+    const int s = blockIdx.x % S;
+    const int start = s * slice_len;
+    const int n_s = min(slice_len, n - start);
+    uint32_t *wss = ws + b * 4 * n + 4ll * start;
+    for (int t = threadIdx.x; t < TOPK_SEL_BINS; t += TOPK_THREADS) s_hist[t] = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (int e = threadIdx.x; e < n_s; e += TOPK_THREADS) {
+        const uint32_t key = frcnn_score_key(NCHW ? rpn_score(L, (int)b, start + e) : scores[b * n + start + e]);
+        wss[e] = key;
+        atomicAdd(&s_hist[key >> (32 - TOPK_SEL_BITS)], 1u);
+    }
+    __syncthreads();
+    unsigned *h = hist + (long long)blockIdx.x * TOPK_SEL_BINS;
+    for (int t = threadIdx.x; t < TOPK_SEL_BINS; t += TOPK_THREADS) h[t] = s_hist[t];
+}
+
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_pick_kernel(const unsigned *__restrict__ hist, int S, int k, uint32_t *__restrict__ thr_key)
+{
+    __shared__ unsigned s_wsum[TOPK_WAVES];
+    const long long b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // thread t owns the four bins that come (4t)-th .. (4t+3)-th from the TOP
+    unsigned c[4] = {0, 0, 0, 0};
+    for (int s = 0; s < S; ++s) {
+        const unsigned *h = hist + (b * S + s) * TOPK_SEL_BINS + (TOPK_SEL_BINS - 4 - 4 * tid);
+        const uint4 v = *(const uint4 *)h; // bins ascending: v.w is the highest of the four
+        c[0] += v.w; c[1] += v.z; c[2] += v.y; c[3] += v.x;
+    }
+    const unsigned mine = c[0] + c[1] + c[2] + c[3];
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned before = incl - mine;
+    for (int w = 0; w < wave; ++w) before += s_wsum[w];
+    // the thread whose bins take the count of keys from below k to at least k holds the k-th largest key
+    if (before < (unsigned)k && before + mine >= (unsigned)k) {
+        unsigned cum = before;
+        int j = 0;
+        for (; j < 3; ++j) {
+            cum += c[j];
+            if (cum >= (unsigned)k) break;
+        }
+        const unsigned bin = (unsigned)(TOPK_SEL_BINS - 1 - (4 * tid + j));
+        thr_key[b] = bin << (32 - TOPK_SEL_BITS);
+    }
+}
+
+template <int KR>
+__global__ void __launch_bounds__(TOPK_THREADS)
+topk_slice_sort_sel_kernel(int n, int k, int S, int slice_len, int kcap, uint32_t *__restrict__ ws,
+                           const uint32_t *__restrict__ thr_key, uint32_t *__restrict__ skeys,
+                           int32_t *__restrict__ sidx, int32_t *__restrict__ slen)
+{
+    __shared__ int s_wave_sums[TOPK_WAVES];
+    const long long b = blockIdx.x / S;
+    const int s = blockIdx.x % S;
+    const int start = s * slice_len;
+    const int n_s = min(slice_len, n - start);
+    const long long list = (b * S + s) * kcap;
+    uint32_t *wss = ws + b * 4 * n + 4ll * start; // [0, n_s): the slice's keys; [n_s, 2 n_s): where a survivor came from
+    const uint32_t T = thr_key[b];
+    // In-place compaction, 4096 places at a time (four consecutive ones per thread): a round's keys are all in
+    // registers before anything is written, and a survivor never moves up.
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int kept = 0;
+    for (int c0 = 0; c0 < n_s; c0 += 4 * TOPK_THREADS) {
+        const int e = c0 + 4 * threadIdx.x;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        if (e + 3 < n_s) {
+            q = *(const uint4 *)(wss + e); // (a slice's buffer starts on a multiple of four words)
+        } else {
+            if (e < n_s) q.x = wss[e];
+            if (e + 1 < n_s) q.y = wss[e + 1];
+            if (e + 2 < n_s) q.z = wss[e + 2];
+        }
+        const bool k0 = e < n_s && q.x >= T, k1 = e + 1 < n_s && q.y >= T, k2 = e + 2 < n_s && q.z >= T,
+                   k3 = e + 3 < n_s && q.w >= T;
+        const int mine = (int)k0 + (int)k1 + (int)k2 + (int)k3;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wave_sums[wave] = incl;
+        __syncthreads(); // (also: every key of the round is in registers)
+        int pos = kept + incl - mine, total = 0;
+#pragma unroll
+        for (int w = 0; w < TOPK_WAVES; ++w) {
+            const int v = s_wave_sums[w];
+            pos += w < wave ? v : 0;
+            total += v;
+        }
+        __syncthreads(); // the sums have been read
+        if (k0) { wss[pos] = q.x; wss[n_s + pos] = (uint32_t)e; ++pos; }
+        if (k1) { wss[pos] = q.y; wss[n_s + pos] = (uint32_t)(e + 1); ++pos; }
+        if (k2) { wss[pos] = q.z; wss[n_s + pos] = (uint32_t)(e + 2); ++pos; }
+        if (k3) { wss[pos] = q.w; wss[n_s + pos] = (uint32_t)(e + 3); ++pos; }
+        kept += total;
+    }
+    __syncthreads();
+    const int k_s = min(k, kept);
+    CompactKeys src;
+    src.keys = wss;
+    src.orig = wss + n_s;
+    // (the sort's first pass has every key and index in registers before it writes; its buffers may overlap them)
+    topk_sort_body<KR, true>(src, kept, k_s, skeys + list, sidx + list, wss);
+    if (threadIdx.x == 0) slen[b * S + s] = k_s;
+}
+
 // number of leading elements of a descending list that go before key K: those >= K (or_equal) or > K
 __device__ __forceinline__ int topk_count_before(const uint32_t *list, int len, uint32_t K, bool or_equal)
 {
@@ -794,14 +941,16 @@ __device__ __forceinline__ int topk_merge_count(const uint32_t *__restrict__ bas
 
 __global__ void __launch_bounds__(TOPK_MERGE_THREADS)
 topk_merge_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict__ sidx, int n, int k, int S,
-                  int slice_len, int kcap, float *__restrict__ val_out, int32_t *__restrict__ idx_out)
+                  int slice_len, int kcap, const int32_t *__restrict__ slen, float *__restrict__ val_out,
+                  int32_t *__restrict__ idx_out)
 {
     __shared__ uint32_t s_win[TOPK_MERGE_WIN];
     __shared__ int s_posF[TOPK_MAX_SLICES], s_posL[TOPK_MAX_SLICES], s_woff[TOPK_MAX_SLICES + 1];
     const long long b = blockIdx.z;
     const int s = blockIdx.y;
     const int i0 = blockIdx.x * TOPK_MERGE_THREADS;
-    const int len_s = min(k, min(slice_len, n - s * slice_len));
+    // list lengths: what the slice could hold, or (selective variant) what it listed
+    const int len_s = slen ? slen[b * S + s] : min(k, min(slice_len, n - s * slice_len));
     if (i0 >= len_s) return;
     const int iend = min(i0 + TOPK_MERGE_THREADS, len_s);
     const uint32_t *lists = skeys + b * S * kcap;
@@ -827,7 +976,7 @@ topk_merge_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict_
             const uint32_t K = q < S ? Kf : Kl;
             const uint32_t *list = lists + (long long)o * kcap;
             const bool or_equal = o < s;
-            int lo = 0, hi = o == s ? 0 : min(k, min(slice_len, n - o * slice_len));
+            int lo = 0, hi = o == s ? 0 : (slen ? slen[b * S + o] : min(k, min(slice_len, n - o * slice_len)));
             while (__any(hi > lo)) {
                 const int w = hi - lo;
                 const int qj = lo + (int)(((long long)(j + 1) * w) >> 4); // a boundary in [lo, hi]
@@ -931,8 +1080,10 @@ extern "C" size_t frcnn_topk_workspace_bytes(int B, int n, int k)
     // enough for every plan frcnn_topk_desc_ex_f32 can choose: one workgroup per image needs 4 n or 4 k words,
     // the split path 4 n for the slice sorts plus the slices' lists (keys and indices, at most n rounded up
     // to whole wave rounds per slice)
+    // (+ the selective variant's per-slice histograms, list lengths and threshold)
     if (n > 8 * TOPK_THREADS)
-        return (size_t)B * (6 * (size_t)n + 2 * 64 * TOPK_MAX_SLICES) * sizeof(uint32_t);
+        return (size_t)B * (6 * (size_t)n + 2 * 64 * TOPK_MAX_SLICES + (size_t)TOPK_MAX_SLICES * (TOPK_SEL_BINS + 1) + 64) *
+                   sizeof(uint32_t) + 16;
     const size_t per = topk_use_sort(n, k) ? (size_t)n : (size_t)k;
     return (size_t)B * 4 * per * sizeof(uint32_t);
 }
@@ -949,6 +1100,17 @@ static void topk_launch_slices(const float *scores, const RpnLevels *levels, int
                            sp.S, sp.slice_len, sp.kcap, ws, skeys, sidx);
 }
 
+template <int KR>
+static void topk_launch_slices_sel(int B, int n, int k, const TopkSplit &sp, uint32_t *ws, const uint32_t *thr,
+                                   uint32_t *skeys, int32_t *sidx, int32_t *slen, hipStream_t stream)
+{
+    hipLaunchKernelGGL((topk_slice_sort_sel_kernel<KR>), dim3(B * sp.S), dim3(TOPK_THREADS), 0, stream, n, k, sp.S,
+                       sp.slice_len, sp.kcap, ws, thr, skeys, sidx, slen);
+}
+
+// k at most a quarter of n: filter before sorting (see topk_slice_hist_kernel)
+static bool topk_selective(int n, int k) { return 4LL * k <= n; }
+
 // slice sorts + merge; scores == nullptr: read the level table instead
 static int topk_run_split(const float *scores, const RpnLevels *levels, int B, int n, int k, const TopkSplit &sp,
                           float *val_out, int32_t *idx_out, void *workspace, hipStream_t stream)
@@ -956,8 +1118,35 @@ static int topk_run_split(const float *scores, const RpnLevels *levels, int B, i
     uint32_t *ws = (uint32_t *)workspace;
     uint32_t *skeys = ws + (size_t)B * 4 * n;
     int32_t *sidx = (int32_t *)(skeys + (size_t)B * sp.S * sp.kcap);
+    // behind the lists' largest extent (B * (2 n + 2 * 64 * TOPK_MAX_SLICES) words): histograms, lengths, thresholds
+    unsigned *hist = (unsigned *)(ws + ((size_t)B * (6 * (size_t)n + 2 * 64 * TOPK_MAX_SLICES) + 3) / 4 * 4); // 16-byte aligned rows
+    int32_t *slen = (int32_t *)(hist + (size_t)B * TOPK_MAX_SLICES * TOPK_SEL_BINS);
+    uint32_t *thr = (uint32_t *)(slen + (size_t)B * TOPK_MAX_SLICES);
     const int rounds = (sp.slice_len + TOPK_THREADS - 1) / TOPK_THREADS;
-    if (rounds <= 2)
+    const bool sel = topk_selective(n, k);
+    if (sel) {
+        if (levels)
+            hipLaunchKernelGGL((topk_slice_hist_kernel<true>), dim3(B * sp.S), dim3(TOPK_THREADS), 0, stream,
+                               (const float *)nullptr, *levels, n, sp.S, sp.slice_len, ws, hist);
+        else {
+            RpnLevels none = {};
+            hipLaunchKernelGGL((topk_slice_hist_kernel<false>), dim3(B * sp.S), dim3(TOPK_THREADS), 0, stream, scores,
+                               none, n, sp.S, sp.slice_len, ws, hist);
+        }
+        FRCNN_CHECK_LAUNCH("topk_slice_hist");
+        hipLaunchKernelGGL(topk_pick_kernel, dim3(B), dim3(TOPK_THREADS), 0, stream, hist, sp.S, k, thr);
+        FRCNN_CHECK_LAUNCH("topk_pick");
+        if (rounds <= 2)
+            topk_launch_slices_sel<2>(B, n, k, sp, ws, thr, skeys, sidx, slen, stream);
+        else if (rounds <= 4)
+            topk_launch_slices_sel<4>(B, n, k, sp, ws, thr, skeys, sidx, slen, stream);
+        else if (rounds <= 8)
+            topk_launch_slices_sel<8>(B, n, k, sp, ws, thr, skeys, sidx, slen, stream);
+        else if (rounds <= 13)
+            topk_launch_slices_sel<13>(B, n, k, sp, ws, thr, skeys, sidx, slen, stream);
+        else
+            topk_launch_slices_sel<TOPK_SORT_KR>(B, n, k, sp, ws, thr, skeys, sidx, slen, stream);
+    } else if (rounds <= 2)
         topk_launch_slices<2>(scores, levels, B, n, k, sp, ws, skeys, sidx, stream);
     else if (rounds <= 4)
         topk_launch_slices<4>(scores, levels, B, n, k, sp, ws, skeys, sidx, stream);
@@ -969,8 +1158,8 @@ static int topk_run_split(const float *scores, const RpnLevels *levels, int B, i
         topk_launch_slices<TOPK_SORT_KR>(scores, levels, B, n, k, sp, ws, skeys, sidx, stream);
     FRCNN_CHECK_LAUNCH("topk_slice_sort");
     hipLaunchKernelGGL(topk_merge_kernel, dim3((sp.kcap + TOPK_MERGE_THREADS - 1) / TOPK_MERGE_THREADS, sp.S, B),
-                       dim3(TOPK_MERGE_THREADS), 0, stream, skeys, sidx, n, k, sp.S, sp.slice_len, sp.kcap, val_out,
-                       idx_out);
+                       dim3(TOPK_MERGE_THREADS), 0, stream, skeys, sidx, n, k, sp.S, sp.slice_len, sp.kcap,
+                       sel ? slen : (const int32_t *)nullptr, val_out, idx_out);
     FRCNN_CHECK_LAUNCH("topk_merge");
     return FRCNN_OK;
 }
