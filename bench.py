@@ -106,6 +106,7 @@ class Path:
         # NMS launches bounded by what the finished steps needed (ops.NmsRounds: same keep lists; the first steps of a
         # workload, before any has finished, enqueue every round)
         self.nms_rounds = ops.NmsRounds()
+        self.path_ws = None
         self.dev = dev
         self.ag = AnchorGenerator()
         self.pool = ROIPooling(['1'], [7, 7], 2)
@@ -133,6 +134,16 @@ class Path:
                 ev.append((name, e))
 
         mark("start")
+        if self.in_place and (ev is None or only_roi):
+            # the proposal half as the RPN module runs it: ONE library call (ops.rpn_proposals_nchw); the staged form
+            # below, same kernels and results, is what the instrumented steps time stage by stage
+            props, n_keep, self.path_ws = ops.rpn_proposals_nchw([cls], [reg], anchors, PRE_NMS, IMG_H, IMG_W, MIN_SIZE,
+                                                                 NMS_THR, POST_NMS, rounds=self.nms_rounds,
+                                                                 workspace=self.path_ws)
+            mark("gather")
+            out, total = self.pool.forward_padded({'1': feat}, props, n_keep, [(IMG_H, IMG_W)])
+            mark("roi_align")
+            return props, n_keep, out, total
         if self.in_place:  # RPN/rpn.py:56-57 never materialised: the head's NCHW outputs are read where they lie
             top_val, top_idx = ops.topk_desc_nchw([cls], PRE_NMS)
             mark("topk")

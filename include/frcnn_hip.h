@@ -129,6 +129,23 @@ int frcnn_decode_clip_filter_nchw_f32(const float *anchors, int64_t anchor_batch
                                       float *scores_out, int32_t *src_out, int32_t *count_out,
                                       void *stream);
 
+/* ---- the proposal half in one call -------------------------------------------------------------
+ * RPN/rpn.py:54-85 for the whole batch: top-k of the head's NCHW scores (:65-67), decode + clip + small-box filter
+ * (:68-83), NMS (:84) and the gather of the kept boxes (:85) -- frcnn_topk_desc_nchw_f32,
+ * frcnn_decode_clip_filter_nchw_f32, frcnn_nms_sorted_rounds_f32 and frcnn_gather_boxes_f32 enqueued back to back on
+ * `stream`, their intermediates in one caller workspace of frcnn_rpn_proposals_workspace_bytes(B, A, k, max_keep)
+ * bytes (contents on entry do not matter).  Same results as the four calls; one foreign call and no allocation per
+ * step for the host.  Sizes: those frcnn_topk_desc_nchw_supported accepts (A > 8192, max_slices != 1).
+ * props_out: (B, max_keep, 4), zero rows after n_keep_out[b]; max_rounds / rounds_used as in
+ * frcnn_nms_sorted_rounds_f32 (0 / NULL: every round). */
+size_t frcnn_rpn_proposals_workspace_bytes(int B, int A, int k, int max_keep);
+int frcnn_rpn_proposals_nchw_f32(const float *const *cls_host, const float *const *reg_host,
+                                 const int32_t *hw_host, int n_levels, int na, const float *anchors,
+                                 int64_t anchor_batch_stride, int B, int k, float image_h, float image_w,
+                                 float min_size, double nms_threshold, int max_keep, float *props_out,
+                                 int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
+                                 int max_slices, int max_rounds, int32_t *rounds_used, void *stream);
+
 /* ---- K4 NMS ----------------------------------------------------------------------------------
  * torchvision.ops.nms as called at RPN/rpn.py:84 and ROIHead/roi_head.py:215, batched.
  * boxes: (B, max_n, 4), each image's rows ALREADY in candidate order (descending score);

@@ -54,15 +54,18 @@ class RPN(Module):
         k = min(self.num_pre_nms, A)                                           # rpn.py:65
         info = batch_image_info
         if ops.rpn_in_place_supported(list_cls, k, self.topk_max_slices):
-            # rpn.py:56-57 never materialised: top-k and decode read the head's NCHW outputs where they lie
-            top_val, top_idx = ops.topk_desc_nchw(list_cls, k, max_slices=self.topk_max_slices)   # rpn.py:66-67
-            boxes, _, _, count = ops.decode_clip_filter_nchw(                  # rpn.py:68-69,75,81-83
-                anchors, list_regs, top_idx, top_val, info[1], info[2], self.proposal_min_size)
-        else:
-            scores, deltas = ops.rpn_flatten(list_cls, list_regs)               # rpn.py:56-57
-            top_val, top_idx = ops.topk_desc(scores, k, max_slices=self.topk_max_slices)   # rpn.py:66-67
-            boxes, _, _, count = ops.decode_clip_filter(                       # rpn.py:68-69,75,81-83
-                anchors, deltas, top_idx, top_val, info[1], info[2], self.proposal_min_size)
+            # rpn.py:56-57 never materialised, and rpn.py:65-85 as ONE library call: top-k and decode read the head's
+            # NCHW outputs where they lie, NMS and the gather follow on the same stream, intermediates in one
+            # workspace kept across steps
+            props, n_keep, self._path_ws = ops.rpn_proposals_nchw(
+                list_cls, list_regs, anchors, k, info[1], info[2], self.proposal_min_size, self.nms_threshold,
+                self.num_post_nms, max_slices=self.topk_max_slices, rounds=self.nms_rounds,
+                workspace=getattr(self, "_path_ws", None))
+            return props, n_keep
+        scores, deltas = ops.rpn_flatten(list_cls, list_regs)               # rpn.py:56-57
+        top_val, top_idx = ops.topk_desc(scores, k, max_slices=self.topk_max_slices)   # rpn.py:66-67
+        boxes, _, _, count = ops.decode_clip_filter(                       # rpn.py:68-69,75,81-83
+            anchors, deltas, top_idx, top_val, info[1], info[2], self.proposal_min_size)
         keep, n_keep = ops.nms_sorted(boxes, count, self.nms_threshold, self.num_post_nms,  # rpn.py:84
                                       rounds=self.nms_rounds)
         props = ops.gather_boxes(boxes, keep, n_keep)                          # rpn.py:85

@@ -37,6 +37,9 @@ SIGNATURES = {
     "frcnn_topk_desc_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _Z, _I, _P]),
     "frcnn_decode_clip_filter_nchw_f32": (_I, [_P, _L, _P, _P, _I, _I, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P,
                                                _P]),
+    "frcnn_rpn_proposals_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "frcnn_rpn_proposals_nchw_f32": (_I, [_P, _P, _P, _I, _I, _P, _L, _I, _I, _F, _F, _F, _D, _I, _P, _P, _P, _Z, _I, _I,
+                                          _P, _P]),
     "frcnn_nms_workspace_bytes": (_Z, [_I, _I]),
     "frcnn_nms_sorted_f32": (_I, [_P, _P, _I, _I, _D, _I, _P, _P, _P, _Z, _P]),
     "frcnn_nms_sorted_rounds_f32": (_I, [_P, _P, _I, _I, _D, _I, _P, _P, _P, _Z, _I, _P, _P]),

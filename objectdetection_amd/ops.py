@@ -193,6 +193,49 @@ def decode_clip_filter_nchw(anchors, list_regs, top_idx, top_score, image_h, ima
     return boxes, scores, src, count
 
 
+def rpn_proposals_nchw(list_cls, list_regs, anchors, k, image_h, image_w, min_size, nms_threshold, max_keep,
+                       max_slices=0, rounds=None, workspace=None):
+    """RPN/rpn.py:54-85 in one library call (frcnn_rpn_proposals_nchw_f32): topk_desc_nchw -> decode_clip_filter_nchw
+    -> nms_sorted -> gather_boxes with their intermediates in one workspace -- same results, a quarter of the host
+    work.  -> (props (B,max_keep,4) zero-padded, n_keep (B) int32, workspace) ; pass the returned workspace back in
+    to reuse it (it is as large as the sizes need, or a new one is made)."""
+    _need_gpu(anchors, *list_cls, *list_regs)
+    B, na = list_cls[0].shape[0], list_cls[0].shape[1]
+    ts_c, ptrs_c, hw = _level_table(list_cls, na, 1)
+    ts_r, ptrs_r, hw_r = _level_table(list_regs, na, 4)
+    if list(hw) != list(hw_r):
+        raise ValueError("rpn_proposals_nchw: score and delta maps disagree in size")
+    A = na * sum(hw[2 * i] * hw[2 * i + 1] for i in range(len(ts_c)))
+    anchors = _f32c(anchors)
+    if anchors.dim() == 2:
+        stride = 0
+        if anchors.shape[0] != A:
+            raise ValueError("anchors (%d) and head outputs (%d) disagree" % (anchors.shape[0], A))
+    else:
+        stride = A * 4
+        if anchors.shape[0] != B or anchors.shape[1] != A:
+            raise ValueError("anchors %s vs head outputs (B=%d, A=%d)" % (tuple(anchors.shape), B, A))
+    dev = ts_c[0].device
+    k, max_keep = int(k), int(max_keep)
+    lib = _lib.load()
+    nbytes = lib.frcnn_rpn_proposals_workspace_bytes(B, A, k, max_keep)
+    if workspace is None or workspace.numel() < nbytes or workspace.device != dev:
+        workspace = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+    props = torch.empty((B, max_keep, 4), dtype=torch.float32, device=dev)
+    n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
+    max_rounds, used = 0, None
+    if rounds is not None and lib.frcnn_nms_workspace_bytes(B, k) > 0:
+        max_rounds, used = rounds.bound((dev.index, B, k, max_keep, float(nms_threshold)), B)
+    with torch.cuda.device(dev):
+        rc = lib.frcnn_rpn_proposals_nchw_f32(
+            ctypes.cast(ptrs_c, ctypes.c_void_p), ctypes.cast(ptrs_r, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p),
+            len(ts_c), na, _ptr(anchors), stride, B, k, float(image_h), float(image_w), float(min_size),
+            float(nms_threshold), max_keep, _ptr(props), _ptr(n_keep), _ptr(workspace), workspace.numel(),
+            int(max_slices), max_rounds, used.data_ptr() if used is not None else None, _stream())
+    _lib.check(rc, "rpn_proposals_nchw")
+    return props, n_keep, workspace
+
+
 # ------------------------------------------------------------------ K3 decode / clip / filter
 def box_regression(box, regs):
     _need_gpu(box, regs)

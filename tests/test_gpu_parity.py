@@ -310,6 +310,41 @@ def test_topk_split_matches_single_workgroup(dev, oracle, kind, B, n, k):
     assert torch.equal(i, ref_i)
 
 
+@pytest.mark.parametrize("fsz,B,k,P", [([(37, 62)], 3, 12000, 2000), ([(13, 21), (25, 42), (50, 84), (100, 168)], 2, 30000, 2000),
+                                        ([(40, 50)], 1, 18000, 300)])
+def test_rpn_proposals_one_call_matches_stages(dev, fsz, B, k, P):
+    """frcnn_rpn_proposals_nchw_f32 (RPN/rpn.py:54-85 in one library call, intermediates in one workspace) against the
+    four stage entry points: same proposals, same counts, bit for bit -- with a fresh workspace full of 0xFF, a
+    reused one, and with the NMS rounds bounded by an NmsRounds."""
+    from objectdetection_amd import ops
+    from objectdetection_amd.RPN.anchor_generator import AnchorGenerator
+    rng = np.random.default_rng(len(fsz) * 100 + B)
+    na, Himg, Wimg = 9, 600.0 if len(fsz) == 1 else 800.0, 1000.0 if len(fsz) == 1 else 1344.0
+    A = sum(h * w for h, w in fsz) * na
+    sc = np.stack([tie_free_scores(rng, A) for _ in range(B)])
+    cls, reg, off = [], [], 0
+    for h, w in fsz:
+        n = h * w * na
+        cls.append(T(sc[:, off:off + n].reshape(B, h, w, na).transpose(0, 3, 1, 2).copy(), dev))
+        reg.append(T((rng.standard_normal((B, 4 * na, h, w)) * 0.3).astype(np.float32), dev))
+        off += n
+    anchors = torch.cat([a[0].reshape(-1, 4) for a in AnchorGenerator()((B, int(Himg), int(Wimg)), cls)], 0)
+    tv, ti = ops.topk_desc_nchw(cls, k)
+    boxes, _, _, count = ops.decode_clip_filter_nchw(anchors, reg, ti, tv, Himg, Wimg, 1e-3)
+    keep, nk = ops.nms_sorted(boxes, count, 0.7, P)
+    ref = ops.gather_boxes(boxes, keep, nk)
+    lib_bytes = ops._lib.load().frcnn_rpn_proposals_workspace_bytes(B, A, k, P)
+    ws = torch.full((lib_bytes,), 0xFF, dtype=torch.uint8, device=dev)
+    rounds = ops.NmsRounds()
+    for _ in range(3):
+        props, n_keep, ws2 = ops.rpn_proposals_nchw(cls, reg, anchors, k, Himg, Wimg, 1e-3, 0.7, P, rounds=rounds,
+                                                    workspace=ws)
+        torch.cuda.synchronize()
+        assert ws2 is ws
+        assert torch.equal(n_keep, nk)
+        assert torch.equal(props, ref)
+
+
 def test_rpn_stages_golden(dev):
     """RPN/rpn.py:55-83 on the HIP path vs what the reference's own functions produced."""
     from objectdetection_amd import ops
