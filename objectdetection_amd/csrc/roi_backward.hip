@@ -9,8 +9,9 @@
 // scatter needs no atomics: RoIAlign's weights are separable, so per RoI the update of a channel is Wy^T (G Wx), two
 // small matrix products that run on the fp32 MFMA (see roi_align_plane_backward_kernel); HBM sees grad_out once plus
 // one write of the planes, and with one workgroup per (image, chunk) the result is deterministic.  Planes too large
-// for four channels of them to fit LDS (FPN P3 / P2 at 800 x 1344) fall back to global atomics, whose sum order is
-// not fixed (as in torchvision).
+// for four channels of them to fit LDS (FPN P3 / P2 at 800 x 1344) are walked window by window
+// (roi_align_window_backward_kernel) and added up with global atomics, whose sum order is not fixed (as in
+// torchvision); shapes outside all of that (other bin counts / sampling ratios) scatter per tap with global atomics.
 #include <math.h>
 
 #include "common.h"
@@ -139,6 +140,109 @@ __device__ __forceinline__ void rab_scatter(const RabG &g, const RabLane &L, con
     }
 }
 
+// 64 candidate RoIs, one per lane (live: to be walked; rec: its record; jidx: its row among the image's RoIs; every
+// wave of the workgroup holds the same values): footprints and table sizes, then batch after batch -- as many RoIs as
+// the table space holds -- the tables are built by all waves and every wave walks the batch for its two channels.
+// The planes are PW cells wide and start at cell (oy, ox) of the H x W map.  Contains workgroup barriers.
+__device__ __forceinline__ void rab_walk64(bool live, const float4 rec, int jidx, int n_cand, int H, int W, int PW, int oy,
+                                           int ox, float *s_tab, int cap, int nw, int wave, int lane, bool has0,
+                                           const float *__restrict__ gb, int C, const RabLane &GL, char *lds,
+                                           const unsigned (&cell_v)[4], unsigned dummy)
+{
+    const int q = lane >> 4, li = lane & 15;
+    int ymin = 0, ymax = 0, xmin = 0, xmax = 0;
+    live = axis_range(rec.y, rec.w, H, ymin, ymax) && live;
+    live = axis_range(rec.x, rec.z, W, xmin, xmax) && live;
+    const int ny = ymax - ymin + 1, nx = xmax - xmin + 1;
+    const int ent = live ? ny + nx : 0; // <= H + W <= cap
+    int pre = ent; // inclusive prefix over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(pre, o);
+        pre += lane >= o ? t : 0;
+    }
+    int done = 0, base = 0;
+    while (done < n_cand) {
+        // ---- the batch: candidates done .. done + m - 1, as many as the table space holds (at least one)
+        const unsigned long long fit = __ballot(lane >= done && pre - base <= cap);
+        const unsigned long long miss = ~fit >> done;
+        int m = miss ? __ffsll((long long)miss) - 1 : 64 - done;
+        m = min(m, n_cand - done);
+        const int my_off = pre - ent - base; // first entry of this lane's RoI
+        __syncthreads(); // the previous batch's tables have been used
+        for (int g = wave * 4; g < m; g += nw * 4) {
+            // ---- tables of RoIs done + g .. + 3: 16 lanes per RoI, lane = (axis, bin) for the scatter
+            const int src = min(done + g + (lane >> 4), 63);
+            const bool mine = g + (lane >> 4) < m;
+            const int src_ent = __shfl(ent, src); // (every lane takes part: the source lanes are anywhere in the wave)
+            const int e_ent = mine ? src_ent : 0;
+            const int e_off = __shfl(my_off, src);
+            const int e_ymin = __shfl(ymin, src), e_ny = __shfl(ny, src), e_xmin = __shfl(xmin, src);
+            const float e_sx = __shfl(rec.x, src), e_sy = __shfl(rec.y, src);
+            const float e_bw = __shfl(rec.z, src), e_bh = __shfl(rec.w, src);
+            float4 *t4 = (float4 *)s_tab + e_off * 2;
+            for (int i = lane & 15; i < e_ent * 2; i += 16) t4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int axis = (lane >> 3) & 1, p = lane & 7;
+            if (e_ent > 0 && p < 7) {
+                const float start = axis ? e_sx : e_sy, bin = axis ? e_bw : e_bh;
+                const float k = axis ? 1.0f : 0.25f;
+                float *col = s_tab + (e_off + (axis ? e_ny - e_xmin : -e_ymin)) * 8 + p;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const AxisSample a = axis_sample(start + (float)p * bin + ((float)s + 0.5f) * bin / 2.0f, axis ? W : H);
+                    if (a.ok) { // (a sample outside the map sends nothing)
+                        col[a.lo * 8] += a.wlo * k;
+                        col[a.hi * 8] += a.whi * k;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (has0) {
+            // ---- this wave's two channels over the batch's RoIs, grad_out of the next RAB_DEPTH RoIs in flight
+            unsigned long long todo = __ballot(ent > 0) & (m >= 64 ? ~0ull : (((1ull << m) - 1ull) << done));
+            auto next = [&]() -> int {
+                if (!todo) return -1;
+                const int e = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                return e;
+            };
+            const int e_first = next();
+            if (e_first >= 0) {
+                RabG G[RAB_DEPTH];
+                int E[RAB_DEPTH];
+                E[0] = e_first;
+#pragma unroll
+                for (int d = 1; d < RAB_DEPTH; ++d) E[d] = next();
+#pragma unroll
+                for (int d = 0; d < RAB_DEPTH; ++d) rab_load(G[d], gb, __builtin_amdgcn_readlane(jidx, E[d] >= 0 ? E[d] : e_first), C, GL);
+                bool more = true;
+                while (more) {
+#pragma unroll
+                    for (int d = 0; d < RAB_DEPTH; ++d) {
+                        if (E[d] < 0) {
+                            more = false;
+                            break;
+                        }
+                        const int e = E[d];
+                        const int e_off = __builtin_amdgcn_readlane(my_off, e);
+                        const int e_ymin = __builtin_amdgcn_readlane(ymin, e), e_ny = __builtin_amdgcn_readlane(ny, e);
+                        const int e_xmin = __builtin_amdgcn_readlane(xmin, e), e_nx = __builtin_amdgcn_readlane(nx, e);
+                        rab_wait(G[d]);
+                        rab_scatter(G[d], GL, s_tab, e_off, e_ymin - oy, e_ny, e_xmin - ox, e_nx, PW, q, li, lds, cell_v, dummy);
+                        E[d] = next();
+                        rab_load(G[d], gb, __builtin_amdgcn_readlane(jidx, E[d] >= 0 ? E[d] : e_first), C, GL);
+                    }
+                }
+            }
+        }
+        base = __builtin_amdgcn_readlane(pre, done + m - 1);
+        done += m;
+    }
+}
+
 // Workgroup = (image, chunk of 2 nw channels, RoI split), nw waves: WAVE w OWNS CHANNELS c0 + 2w, c0 + 2w + 1 and
 // their gradient planes in LDS (interleaved: one float2 per cell), so no two waves ever add into the same plane, and
 // inside a wave the lanes are distinct CELLS of the RoI's footprint: the scatter needs no atomics, it is ds_read_b64,
@@ -205,103 +309,13 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
         // ---- lane = candidate RoI jw + lane: footprint and table size (every wave computes the same values)
         bool live = jw + lane < j_end;
         float4 rec = make_float4(0.0f, 0.0f, 1.0f, 1.0f);
-        int ymin = 0, ymax = 0, xmin = 0, xmax = 0;
         if (live) {
             const float4 box = pb[jw + lane];
             if (n_levels > 1 && map_level(box, k_min, k_max) != level) live = false;
             rec = rab_record(box, scale);
         }
-        live = axis_range(rec.y, rec.w, H, ymin, ymax) && live;
-        live = axis_range(rec.x, rec.z, W, xmin, xmax) && live;
-        const int ny = ymax - ymin + 1, nx = xmax - xmin + 1;
-        const int ent = live ? ny + nx : 0; // <= H + W <= cap
-        int pre = ent; // inclusive prefix over the lanes
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(pre, o);
-            pre += lane >= o ? t : 0;
-        }
-        const int n_cand = min(64, j_end - jw);
-        int done = 0, base = 0;
-        while (done < n_cand) {
-            // ---- the batch: candidates done .. done + m - 1, as many as the table space holds (at least one)
-            const unsigned long long fit = __ballot(lane >= done && pre - base <= cap);
-            const unsigned long long miss = ~fit >> done;
-            int m = miss ? __ffsll((long long)miss) - 1 : 64 - done;
-            m = min(m, n_cand - done);
-            const int my_off = pre - ent - base; // first entry of this lane's RoI
-            __syncthreads(); // the previous batch's tables have been used
-            for (int g = wave * 4; g < m; g += nw * 4) {
-                // ---- tables of RoIs done + g .. + 3: 16 lanes per RoI, lane = (axis, bin) for the scatter
-                const int src = min(done + g + (lane >> 4), 63);
-                const bool mine = g + (lane >> 4) < m;
-                const int src_ent = __shfl(ent, src); // (every lane takes part: the source lanes are anywhere in the wave)
-                const int e_ent = mine ? src_ent : 0;
-                const int e_off = __shfl(my_off, src);
-                const int e_ymin = __shfl(ymin, src), e_ny = __shfl(ny, src), e_xmin = __shfl(xmin, src);
-                const float e_sx = __shfl(rec.x, src), e_sy = __shfl(rec.y, src);
-                const float e_bw = __shfl(rec.z, src), e_bh = __shfl(rec.w, src);
-                float4 *t4 = (float4 *)s_tab + e_off * 2;
-                for (int i = lane & 15; i < e_ent * 2; i += 16) t4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const int axis = (lane >> 3) & 1, p = lane & 7;
-                if (e_ent > 0 && p < 7) {
-                    const float start = axis ? e_sx : e_sy, bin = axis ? e_bw : e_bh;
-                    const float k = axis ? 1.0f : 0.25f;
-                    float *col = s_tab + (e_off + (axis ? e_ny - e_xmin : -e_ymin)) * 8 + p;
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const AxisSample a = axis_sample(start + (float)p * bin + ((float)s + 0.5f) * bin / 2.0f, axis ? W : H);
-                        if (a.ok) { // (a sample outside the map sends nothing)
-                            col[a.lo * 8] += a.wlo * k;
-                            col[a.hi * 8] += a.whi * k;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (has0) {
-                // ---- this wave's two channels over the batch's RoIs, grad_out of the next RAB_DEPTH RoIs in flight
-                unsigned long long todo = __ballot(ent > 0) & (m >= 64 ? ~0ull : (((1ull << m) - 1ull) << done));
-                auto next = [&]() -> int {
-                    if (!todo) return -1;
-                    const int e = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    return e;
-                };
-                const int e_first = next();
-                if (e_first >= 0) {
-                    RabG G[RAB_DEPTH];
-                    int E[RAB_DEPTH];
-                    E[0] = e_first;
-#pragma unroll
-                    for (int d = 1; d < RAB_DEPTH; ++d) E[d] = next();
-#pragma unroll
-                    for (int d = 0; d < RAB_DEPTH; ++d) rab_load(G[d], gb, jw + (E[d] >= 0 ? E[d] : e_first), C, GL);
-                    bool more = true;
-                    while (more) {
-#pragma unroll
-                        for (int d = 0; d < RAB_DEPTH; ++d) {
-                            if (E[d] < 0) {
-                                more = false;
-                                break;
-                            }
-                            const int e = E[d];
-                            const int e_off = __builtin_amdgcn_readlane(my_off, e);
-                            const int e_ymin = __builtin_amdgcn_readlane(ymin, e), e_ny = __builtin_amdgcn_readlane(ny, e);
-                            const int e_xmin = __builtin_amdgcn_readlane(xmin, e), e_nx = __builtin_amdgcn_readlane(nx, e);
-                            rab_wait(G[d]);
-                            rab_scatter(G[d], GL, s_tab, e_off, e_ymin, e_ny, e_xmin, e_nx, W, q, li, lds, cell_v, dummy);
-                            E[d] = next();
-                            rab_load(G[d], gb, jw + (E[d] >= 0 ? E[d] : e_first), C, GL);
-                        }
-                    }
-                }
-            }
-            base = __builtin_amdgcn_readlane(pre, done + m - 1);
-            done += m;
-        }
+        rab_walk64(live, rec, jw + lane, min(64, j_end - jw), H, W, W, 0, 0, s_tab, cap, nw, wave, lane, has0, gb, C, GL, lds,
+                   cell_v, dummy);
     }
     __syncthreads();
     float *out = grad_feat + ((long long)b * C + c0) * HW;
@@ -316,13 +330,115 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
     }
 }
 
+// ---- planes too large for LDS (FPN P3 100 x 168, P2 200 x 336): windows of the gradient plane -----------------------
+// The forward's windows (roi_common.h: RAW_WIN x RAW_WIN cells every RAW_STEP; a RoI belongs to the window that holds
+// its first tap and fits when its last tap is inside too) with the scheme above run on each: workgroup = (window,
+// image, channel split), RABW_PAIRS waves = channel pairs whose 64 x 64 gradient WINDOWS live in LDS.  The window's RoIs
+// are listed once (in index order), then chunk after chunk of 2 RABW_PAIRS channels is zeroed, walked (rab_walk64) and
+// added to grad_feat with global float atomics -- windows overlap, so a cell collects up to four partial sums (and
+// whatever the oversize RoIs send through roi_align_backward_atomic_kernel, launched with the same test inverted);
+// the host entry zeroes grad_feat first.  HBM sees grad_out once; the atomics are coalesced 256-byte rows.
+#define RABW_PAIRS 4
+#define RABW_THREADS (64 * RABW_PAIRS)
+#define RABW_LIST 2048 // RoIs of one image examined per pass (a window's list cannot be longer)
+__global__ void __launch_bounds__(RABW_THREADS)
+roi_align_window_backward_kernel(const float *__restrict__ grad_out, int C, int H, int W,
+                                 const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
+                                 float scale, int level, int n_levels, int k_min, int k_max, int nwy, int nwx,
+                                 int csplit, int B, int tab_off, int cap, float *__restrict__ grad_feat)
+{
+    extern __shared__ __align__(16) float s_dyn[]; // [RABW_PAIRS][64 * 64] float2 windows, then the tables
+    __shared__ int s_list[RABW_LIST];
+    __shared__ int s_wave_sums[RABW_PAIRS];
+    __shared__ int s_off, s_cnt;
+    __shared__ f32x2 s_dummy[64];
+    f32x2 *const s_pl = (f32x2 *)s_dyn;
+    float *const s_tab = s_dyn + tab_off;
+    const int cs = blockIdx.x % csplit;
+    const int grp = blockIdx.x / csplit;
+    const int wid = grp % (nwy * nwx);
+    const int b = grp / (nwy * nwx);
+    const int wy0 = (wid / nwx) * RAW_STEP, wx0 = (wid % nwx) * RAW_STEP;
+    const int wh = min(RAW_WIN, H - wy0), ww = min(RAW_WIN, W - wx0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int HW = H * W;
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int i = 0; i < B; ++i) {
+            int c = count ? count[i] : P;
+            c = c < 0 ? 0 : (c > P ? P : c);
+            if (i < b) off += c;
+            if (i == b) s_cnt = c;
+        }
+        s_off = off;
+    }
+    __syncthreads();
+    const int cnt = s_cnt;
+    const float4 *pb = props + (long long)b * P;
+    char *const lds = (char *)s_dyn;
+    const unsigned dummy = (unsigned)((char *)(s_dummy + lane) - lds);
+    const int q = lane >> 4, li = lane & 15;
+    unsigned cell_v[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) cell_v[v] = (unsigned)((wave * RAW_WIN * RAW_WIN + (4 * q + v) * RAW_WIN + li) * 8);
+    const int chunks = (C + 2 * RABW_PAIRS - 1) / (2 * RABW_PAIRS);
+    for (int seg = 0; seg < cnt; seg += RABW_LIST) {
+        // ---- the window's RoIs among seg .. seg + RABW_LIST - 1, in index order
+        int n_list = 0;
+        for (int i0 = seg; i0 < min(cnt, seg + RABW_LIST); i0 += RABW_THREADS) {
+            const int i = i0 + threadIdx.x;
+            bool mine = false;
+            if (i < min(cnt, seg + RABW_LIST)) {
+                const float4 box = pb[i];
+                const int lv = n_levels > 1 ? map_level(box, k_min, k_max) : 0;
+                const RoiWindow rw = roi_window(roi_record(box, scale), H, W, nwy, nwx);
+                mine = lv == level && rw.fits && rw.win == wid;
+            }
+            int total;
+            const int pos = n_list + frcnn_block_excl_count(mine, s_wave_sums, &total);
+            if (mine) s_list[pos] = i;
+            n_list += total;
+        }
+        __syncthreads();
+        for (int ch = cs; ch < (n_list ? chunks : 0); ch += csplit) {
+            const int c0 = ch * 2 * RABW_PAIRS;
+            const int nc = min(2 * RABW_PAIRS, C - c0);
+            const int ch0 = c0 + 2 * wave;
+            const bool has0 = ch0 < C, has1 = ch0 + 1 < C;
+            const float *gb = grad_out + ((long long)s_off * C + min(ch0, C - 1)) * 49;
+            const RabLane GL = rab_lane(lane, has1 ? 49 : 0);
+            for (int t = threadIdx.x; t < RABW_PAIRS * RAW_WIN * RAW_WIN; t += RABW_THREADS) s_pl[t] = (f32x2){0.0f, 0.0f};
+            __syncthreads();
+            for (int lw = 0; lw < n_list; lw += 64) {
+                const bool live = lw + lane < n_list;
+                const int j = live ? s_list[lw + lane] : 0;
+                const float4 rec = live ? roi_record(pb[j], scale) : make_float4(0.0f, 0.0f, 1.0f, 1.0f);
+                rab_walk64(live, rec, j, min(64, n_list - lw), H, W, RAW_WIN, wy0, wx0, s_tab, cap, RABW_PAIRS, wave, lane,
+                           has0, gb, C, GL, lds, cell_v, dummy);
+            }
+            __syncthreads();
+            // ---- add the windows to the map: rows of ww cells, coalesced
+            const float *s_f = (const float *)s_pl;
+            for (int t = threadIdx.x; t < nc * wh * RAW_WIN; t += RABW_THREADS) {
+                const int c = t / (wh * RAW_WIN), rem = t - c * (wh * RAW_WIN);
+                const int y = rem / RAW_WIN, x = rem - y * RAW_WIN;
+                const float v = s_f[((c >> 1) * RAW_WIN * RAW_WIN + y * RAW_WIN + x) * 2 + (c & 1)];
+                if (x < ww && v != 0.0f)
+                    unsafeAtomicAdd(grad_feat + ((long long)b * C + c0 + c) * HW + (long long)(wy0 + y) * W + wx0 + x, v);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Any plane size / pooled size / sampling ratio: block = (RoI split, 32-channel chunk, image), global float
 // atomics per tap (grad_feat zeroed by the host entry).
 __global__ void __launch_bounds__(256)
 roi_align_backward_atomic_kernel(const float *__restrict__ grad_out, int C, int H, int W,
                                  const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
                                  int pooled_h, int pooled_w, float scale, int sampling_ratio, int level,
-                                 int n_levels, int k_min, int k_max, float *__restrict__ grad_feat)
+                                 int n_levels, int k_min, int k_max, int nwy, int nwx, float *__restrict__ grad_feat)
 {
     __shared__ int s_off, s_cnt;
     const int b = blockIdx.z;
@@ -346,6 +462,8 @@ roi_align_backward_atomic_kernel(const float *__restrict__ grad_out, int C, int 
     for (int j = blockIdx.x; j < cnt; j += gridDim.x) {
         const float4 box = props[(long long)b * P + j];
         if (n_levels > 1 && map_level(box, k_min, k_max) != level) continue;
+        // behind the window kernel: only the RoIs that fit no window (the same test, inverted)
+        if (nwy > 0 && roi_window(roi_record(box, scale), H, W, nwy, nwx).fits) continue;
         float start_w = box.x * scale, start_h = box.y * scale;
         float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
         roi_w = roi_w > 1.0f ? roi_w : 1.0f;
@@ -430,12 +548,40 @@ extern "C" int frcnn_roi_align_batched_backward_f32(const float *grad_out, int B
     }
     hipError_t e = hipMemsetAsync(grad_feat, 0, plane_elems * sizeof(float), st);
     FRCNN_REQUIRE(e == hipSuccess, "roi_align_backward: memset failed: %s", hipGetErrorString(e));
+    int nwy = 0, nwx = 0;
+    if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && (long long)P * 49 < (1ll << 30) &&
+        (long long)H * W < (1ll << 28)) {
+        // plane too large for LDS: windows of it (fine pyramid levels, where RoIs are small)
+        nwy = H <= RAW_WIN ? 1 : (H - RAW_WIN + RAW_STEP - 1) / RAW_STEP + 1;
+        nwx = W <= RAW_WIN ? 1 : (W - RAW_WIN + RAW_STEP - 1) / RAW_STEP + 1;
+        if ((long long)nwy * nwx * B >= (1ll << 24)) {
+            nwy = nwx = 0;
+        } else {
+            const int chunks = (C + 2 * RABW_PAIRS - 1) / (2 * RABW_PAIRS);
+            int csplit = (int)((1024 + (long long)nwy * nwx * B - 1) / ((long long)nwy * nwx * B));
+            csplit = csplit < 1 ? 1 : (csplit > chunks ? chunks : csplit);
+            const int tab_off = RABW_PAIRS * RAW_WIN * RAW_WIN * 2; // floats
+            // beside the windows: the RoI list and the dummies (static), and tables for at least one RoI of a window
+            long long cap = (RAB_LDS_BUDGET - (long long)tab_off * 4 - RABW_LIST * 4 - 64) / 32;
+            if (cap > RAB_TAB_MAX_ENTRIES) cap = RAB_TAB_MAX_ENTRIES;
+            FRCNN_REQUIRE(cap >= 2 * RAW_WIN, "roi_align_backward: internal: table space %lld entries", cap);
+            const size_t lds = (size_t)tab_off * 4 + (size_t)cap * 32;
+            static size_t grantedw[FRCNN_MAX_DEVICES];
+            e = frcnn_reserve_dynamic_lds((const void *)roi_align_window_backward_kernel, lds, grantedw);
+            FRCNN_REQUIRE(e == hipSuccess, "roi_align_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+            hipLaunchKernelGGL(roi_align_window_backward_kernel, dim3((unsigned)(nwy * nwx * B * csplit)),
+                               dim3(RABW_THREADS), lds, st, grad_out, C, H, W, (const float4 *)props, count, P,
+                               spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, csplit, B, tab_off, (int)cap,
+                               grad_feat);
+            FRCNN_CHECK_LAUNCH("roi_align_window_backward");
+        }
+    }
     const int chunks = (C + 31) / 32;
     FRCNN_REQUIRE(chunks <= 65535, "roi_align_backward: too many channels");
     const int splits = P < 256 ? P : 256;
     hipLaunchKernelGGL(roi_align_backward_atomic_kernel, dim3(splits, chunks, B), dim3(256), 0, st, grad_out, C, H, W,
                        (const float4 *)props, count, P, pooled_h, pooled_w, spatial_scale, sampling_ratio, level,
-                       n_levels, k_min, k_max, grad_feat);
+                       n_levels, k_min, k_max, nwy, nwx, grad_feat);
     FRCNN_CHECK_LAUNCH("roi_align_backward_atomic");
     return FRCNN_OK;
 }

@@ -85,3 +85,41 @@ __device__ __forceinline__ AxisSample axis_sample(float v, int n)
     return a;
 }
 
+// ---- windows of a plane too large for LDS (forward: roi_align_window_kernel; backward: its mirror) --------------
+#ifndef RAW_WIN
+#define RAW_WIN 64
+#define RAW_STEP 32
+#define RAW_G 2 // float4 channel groups per workgroup: RAW_WIN^2 * 16 B * RAW_G of LDS
+#endif
+struct RoiWindow {
+    int win;   // iy * nwx + ix
+    bool fits; // every tap of the RoI lies inside that window
+};
+
+__device__ __forceinline__ float4 roi_record(float4 box, float scale)
+{
+    float start_w = box.x * scale, start_h = box.y * scale;
+    float roi_w = box.z * scale - start_w, roi_h = box.w * scale - start_h;
+    roi_w = roi_w > 1.0f ? roi_w : 1.0f;
+    roi_h = roi_h > 1.0f ? roi_h : 1.0f;
+    return make_float4(start_w, start_h, roi_w / 7.0f, roi_h / 7.0f);
+}
+
+// Same expressions as the item loops use for bin 0 / sample 0 and bin 6 / sample 1: sample
+// coordinates grow with (bin, sample), so every tap lies between the first sample's low cell and the
+// last sample's high cell (samples outside the map have zero weight and are relocated by the caller).
+__device__ __forceinline__ RoiWindow roi_window(float4 rec, int H, int W, int nwy, int nwx)
+{
+    const AxisSample yf = axis_sample(rec.y + 0.0f * rec.w + (0.0f + 0.5f) * rec.w / 2.0f, H);
+    const AxisSample yl = axis_sample(rec.y + 6.0f * rec.w + (1.0f + 0.5f) * rec.w / 2.0f, H);
+    const AxisSample xf = axis_sample(rec.x + 0.0f * rec.z + (0.0f + 0.5f) * rec.z / 2.0f, W);
+    const AxisSample xl = axis_sample(rec.x + 6.0f * rec.z + (1.0f + 0.5f) * rec.z / 2.0f, W);
+    const int y_lo = yf.ok ? yf.lo : 0, y_hi = yl.ok ? yl.hi : H - 1;
+    const int x_lo = xf.ok ? xf.lo : 0, x_hi = xl.ok ? xl.hi : W - 1;
+    const int iy = min(y_lo / RAW_STEP, nwy - 1), ix = min(x_lo / RAW_STEP, nwx - 1);
+    RoiWindow r;
+    r.win = iy * nwx + ix;
+    r.fits = y_hi < iy * RAW_STEP + RAW_WIN && x_hi < ix * RAW_STEP + RAW_WIN;
+    return r;
+}
+
