@@ -492,6 +492,7 @@ def main():
         extras.update(targets_microbench(path, dev))
         extras.update(roi_pool_microbench(path, dev))
         extras.update(config5_microbench(dev))
+        extras["next_rows"].update(config5_backward_microbench(dev))
         extras.update(config5_microbench(dev, B=8, reps=3, levels=5))   # SURVEY's extra stress point, A = 805,707
         c64 = config5_microbench(dev, B=64, reps=3)   # BASELINE configs[4] names batch 64
         extras["config5_A200907_k30000_C256_batch64"] = c64["config5_A200907_k30000_C256"]
@@ -809,6 +810,38 @@ def config5_microbench(dev, B=16, reps=5, levels=4):
         "rois_per_step": int(total), "keeps_per_img_mean": float(nk.float().mean()),
         "roi_align_write_GBps": out_bytes / (stage["roi_align"] * 1e-3) / 1e9,
         "roi_align_hbm_frac": out_bytes / (stage["roi_align"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+
+
+def config5_backward_microbench(dev, B=16, reps=3):
+    """RoIAlign backward at config 5 (four FPN levels; the finest one's planes do not fit LDS and are walked window by
+    window): d(sum(out * G)) / d(feature maps) through the autograd wiring of MultiScaleRoIAlign."""
+    from objectdetection_amd import ops
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    x = config5_inputs(B, dev)
+    tv, ti = ops.topk_desc_nchw(x["cls"], 30000)
+    boxes, _, _, count = ops.decode_clip_filter_nchw(x["anchors"], x["reg"], ti, tv, x["Himg"], x["Wimg"], 1e-3)
+    keep, nk = ops.nms_sorted(boxes, count, 0.7, 2000)
+    props = ops.gather_boxes(boxes, keep, nk)
+    feats = [f.requires_grad_(True) for f in x["feats"][::-1]]
+    pool = ROIPooling(['1', '2', '3', '4'], [7, 7], 2)
+    out, total = pool.forward_padded({str(i + 1): f for i, f in enumerate(feats)}, props, nk, [(x["Himg"], x["Wimg"])])
+    G = torch.randn_like(out)
+
+    def run():
+        for f in feats:
+            f.grad = None
+        out.backward(G, retain_graph=True)
+    run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nbytes = int(total) * x["C"] * 49 * 4 + sum(f.numel() for f in feats) * 4
+    return {"roi_align_backward_config5_B16_C256": {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / ms / 1e6,
+                                                    "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS}}
 
 
 def roi_pool_microbench(path, dev):
