@@ -287,7 +287,7 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -439,11 +439,19 @@ def main():
     if args.dry_run:
         dry_run(args, world, rank)
         return
+    # BENCH_REHEARSE_ON_ONE_GPU=1: every rank on GPU 0 with gloo in place of RCCL -- the rank plumbing (image shards,
+    # barrier + max-over-ranks bracket, proposal gather) around the real kernels where only one GPU is at hand; the
+    # ranks share the card, so the line it prints is a rehearsal, not a measurement.
+    rehearse = os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+            local_rank = 0
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         world = dist.get_world_size()  # n_gpus of the line = what RCCL reports
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback for the product path)")
@@ -463,8 +471,12 @@ def main():
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         from objectdetection_amd.sharding import gather_proposals
-        all_props, all_counts = gather_proposals(props, n_keep, dist)
+        if rehearse:  # gloo: the collective runs on host copies
+            all_props, all_counts = gather_proposals(props.cpu(), n_keep.cpu(), dist)
+        else:
+            all_props, all_counts = gather_proposals(props, n_keep, dist)
         assert all_props.shape[0] == world * B
+        assert all_counts.shape[0] == world * B and int(all_counts.min()) >= 0
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
@@ -505,7 +517,8 @@ def main():
             "metric": "images/sec RPN proposal+RoIPool",
             "value": main_res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not rehearse else "synthetic (REHEARSAL: all ranks share GPU 0 over gloo -- not a measurement)",
             "config": {"workload": "BASELINE configs[1] / SURVEY 8d config 2: batch %d x 600x1000 per GPU, 37x62 "
                                    "stride-16 map, A=%d anchors/img, top-%d -> NMS %.1f -> <=%d, RoIAlign 7x7 C=%d, "
                                    "reference (bug-compatible) decode, %s"

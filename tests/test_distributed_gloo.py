@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -71,10 +72,11 @@ def test_two_rank_shard_and_gather(tmp_path, oracle):
     assert ref_c.sum() > 0
 
 
-def _run_bench(cmd, timeout=300):
+def _run_bench(cmd, timeout=300, env=None):
     import json
     import subprocess
-    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
+                       env=dict(os.environ, **env) if env else None)
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     return r.returncode, [json.loads(l) for l in lines], r.stderr.decode()
 
@@ -104,3 +106,17 @@ def test_bench_launcher_reports_a_failed_rank():
     rc, lines, err = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--batch", "-1", "--dry-run"])
     assert rc != 0 and not lines
     assert "ranks exited with" in err
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_for_rehearsal():
+    """The real kernels under the rank plumbing with a single GPU at hand: BENCH_REHEARSE_ON_ONE_GPU=1 puts both ranks
+    on GPU 0 and swaps RCCL for gloo.  Each rank takes its own image shard, the bracket is barrier + max over ranks, the
+    proposals of both ranks are gathered; the line says that it is a rehearsal, not a measurement."""
+    rc, lines, err = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4",
+                                 "--no-extras", "--cpu-sample", "0"], env={"BENCH_REHEARSE_ON_ONE_GPU": "1"})
+    assert rc == 0, err
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["gather_ms"] is not None and line["value"] > 0
+    assert "REHEARSAL" in line["data"] and line["config"]["batch_per_gpu"] == 4
