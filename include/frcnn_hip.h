@@ -168,9 +168,10 @@ int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, 
  * enqueues at most that many rounds and then ONE tail launch that finishes any image that is not done, one
  * workgroup per image: slow when it has to work, and exact -- keep lists never depend on max_rounds
  * (max_rounds <= 0, or min(max_keep, max_n) > 2048: every round, no tail).  rounds_used: (B) int32, device or
- * host-mapped (pinned) memory, or NULL; written once, by the call's last launch: per image the rounds that had
- * work to do, or the total number of rounds for an image the tail had to finish.  A caller feeds
- * max(rounds_used) + 1 of one batch to the next call (objectdetection_amd.ops.NmsRounds). */
+ * host-mapped (pinned) memory, or NULL; written once, by the call's last launch: per image the 64-candidate BLOCKS
+ * that had work to do (16 per round; how far into its last round an image got tells the caller how much slack a
+ * bound has).  A caller feeds ceil((max(rounds_used) + slack) / 16) of one batch to the next call
+ * (objectdetection_amd.ops.NmsRounds: slack = 4 blocks). */
 int frcnn_nms_sorted_rounds_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
                                 double iou_threshold, int max_keep, int32_t *keep_out,
                                 int32_t *n_keep_out, void *workspace, size_t workspace_bytes,

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(NMS_LAZY_THREADS)
 nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image, int max_n,
                 FrcnnThr thr, int max_keep, int cap, int32_t *__restrict__ keep_out,
                 int32_t *__restrict__ n_keep_out, int first_block, const char *resume_ws, size_t resume_stride,
-                int resume_cap, int total_rounds, int32_t *rounds_used)
+                int resume_cap, int32_t *rounds_used)
 {
     // dynamic LDS: [cap] kept boxes (float4), [cap] kept areas, [cap] kept positions
     extern __shared__ float4 s_kbox[];
@@ -97,8 +97,10 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
         const int *state = (const int *)p; // nkeep, dense, rounds
         nk0 = state[0];
         const bool idle = first_block * 64 >= n || nk0 >= max_keep;
-        if (threadIdx.x == 0 && rounds_used) rounds_used[b] = idle ? state[2] : total_rounds;
-        if (idle) return;
+        if (idle) {
+            if (threadIdx.x == 0 && rounds_used) rounds_used[b] = state[2];
+            return;
+        }
         for (int t = threadIdx.x; t < nk0; t += NMS_LAZY_THREADS) {
             s_kbox[t] = kbox[t];
             s_karea[t] = karea[t];
@@ -111,6 +113,7 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
     }
     __syncthreads();
     int nkeep_final = nk0;
+    int blocks_done = first_block; // 64-candidate blocks that had work (the tail reports them)
     for (int c0 = first_block; c0 < Wn; c0 += NMS_LAZY_WAVES) {
         // refill: one coalesced 16-KB read serves the next 16 candidate blocks; no global memory
         // operation is issued inside the per-block loop below, so its barriers are cheap
@@ -194,6 +197,7 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
             }
             __syncthreads();
             nkeep_final = s_nkeep;
+            blocks_done = c + 1;
             if (nkeep_final >= max_keep) {
                 done = true;
                 break;
@@ -205,7 +209,10 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
     nkeep_final = s_nkeep;
     int32_t *keep = keep_out + (long long)b * max_keep;
     for (int t = nk0 + threadIdx.x; t < nkeep_final; t += NMS_LAZY_THREADS) keep[t] = s_kidx[t];
-    if (threadIdx.x == 0) n_keep_out[b] = nkeep_final;
+    if (threadIdx.x == 0) {
+        n_keep_out[b] = nkeep_final;
+        if (resume_ws && rounds_used) rounds_used[b] = blocks_done;
+    }
 }
 
 // ---- round-based NMS --------------------------------------------------------------------------
@@ -228,7 +235,7 @@ struct NmsWs {
     unsigned long long *sup;   // [NMS_RC] this round's pull result (zero between rounds)
     int *nkeep;                // [1]
     int *dense;                // [1] last round left >= NMS_DENSE survivors of the pull: precompute tiles
-    int *rounds;               // [1] rounds that had work to do so far
+    int *rounds;               // [1] 64-candidate blocks that had work to do so far (16 per round)
 };
 
 static size_t nms_ws_stride(int cap)
@@ -435,7 +442,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     __shared__ int s_pos[NMS_RS];      // the list's positions inside the round
     __shared__ unsigned long long s_removed[NMS_RC];
     __shared__ unsigned long long s_K[NMS_RC];
-    __shared__ int s_nkeep;
+    __shared__ int s_nkeep, s_worked;
     const int b = blockIdx.x;
     const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
     const int base = round * NMS_RS;
@@ -536,10 +543,11 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
         unsigned long long removed[NMS_RC];
 #pragma unroll
         for (int cb = 0; cb < NMS_RC; ++cb) removed[cb] = uniform64(s_removed[cb]);
-        int nk = nk0;
+        int nk = nk0, worked = 0;
 #pragma unroll
         for (int c = 0; c < NMS_RC; ++c) {
             if (c < nC && nk < max_keep) {
+                worked = c + 1;
                 const int tb = nms_tile_id(c, c);
                 const unsigned long long col = s_tiles[tb * 64 + lane];
                 // the block's words in the later blocks' tiles: requested together, ahead of the resolve loop
@@ -572,7 +580,10 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
                 }
             }
         }
-        if (lane == 0) s_nkeep = nk;
+        if (lane == 0) {
+            s_nkeep = nk;
+            s_worked = worked;
+        }
     }
     __syncthreads();
     // append the round's keeps to the kept list (list order = candidate order)
@@ -590,9 +601,16 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     if (t == 0) {
         *w.nkeep = s_nkeep;
         *w.dense = dense ? 1 : 0;
-        *w.rounds = round + 1;
+        // 64-candidate blocks that had work so far: where in the round max_keep was reached
+        int in_round = s_worked; // dense: the list is the round itself
+        if (!dense) {            // compacted list: where in the round its last examined entry stood
+            const int last = min(count, s_worked * 64) - 1;
+            in_round = last >= 0 ? s_pos[last] / 64 + 1 : NMS_RC;
+        }
+        const int blocks = round * NMS_RC + in_round;
+        *w.rounds = blocks;
         n_keep_out[b] = s_nkeep;
-        if (rounds_used) rounds_used[b] = round + 1;
+        if (rounds_used) rounds_used[b] = blocks;
     }
 }
 
@@ -619,8 +637,8 @@ static FrcnnThr make_threshold(double thr)
 // image is not done (nms_lazy_kernel's resume form) -- for callers who know from the previous batch how many rounds
 // do any work: rounds after max_keep is reached exit at once, but still cost two launches each (nine of twelve at
 // 12,000 -> 2,000).  The result never depends on max_rounds.  rounds_used (B ints, may be host-mapped memory, may
-// be null): per image, the rounds that had work -- written once, by the call's last launch; the total round count
-// for an image that the tail had to finish.
+// be null): per image, the 64-candidate BLOCKS that had work (16 per round: how far into its last round an image
+// got tells the caller how much slack its bound has) -- written once, by the call's last launch.
 static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B, int max_n,
                           double iou_threshold, int max_keep, int32_t *keep_out, int32_t *n_keep_out,
                           void *workspace, size_t workspace_bytes, int max_rounds, int32_t *rounds_used,
@@ -650,7 +668,7 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
         }
         hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
                            (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out,
-                           n_keep_out, 0, (const char *)nullptr, (size_t)0, 0, 0, (int32_t *)nullptr);
+                           n_keep_out, 0, (const char *)nullptr, (size_t)0, 0, (int32_t *)nullptr);
         FRCNN_CHECK_LAUNCH("nms_lazy");
         return FRCNN_OK;
     }
@@ -689,7 +707,7 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
         }
         hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
                            (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out, n_keep_out,
-                           run * NMS_RC, (const char *)workspace, stride, max_n, rounds, rounds_used);
+                           run * NMS_RC, (const char *)workspace, stride, max_n, rounds_used);
         FRCNN_CHECK_LAUNCH("nms_tail");
     }
     return FRCNN_OK;

@@ -506,17 +506,19 @@ def decode_clip_filter(anchors, deltas, top_idx, top_score, image_h, image_w, mi
 
 # --------------------------------------------------------------------------------------- K4 NMS
 class NmsRounds:
-    """How many rounds of the round-path NMS the caller's recent batches needed, fed forward as the next call's
-    launch bound (frcnn_nms_sorted_rounds_f32).  The kernels leave the per-image round counts of a call in pinned
-    host memory that the GPU writes directly; the host reads whatever has landed -- the counts of the last call
-    that FINISHED, never a synchronisation -- and asks for one round more than their maximum.  Until a first
-    call has finished (or after a batch that needed its tail launch) every round is enqueued, as without it.
-    Keep lists do not depend on the bound; one object per call site and stream."""
+    """How far into the round-path NMS the caller's recent batches got, fed forward as the next call's launch bound
+    (frcnn_nms_sorted_rounds_f32).  The kernels leave, per image, the count of 64-candidate blocks that had work (16
+    per round) in pinned host memory that the GPU writes directly; the host reads whatever has landed -- the counts
+    of the last call that FINISHED, never a synchronisation -- and asks for the rounds that hold their maximum plus
+    `slack` blocks (4 = a quarter of a round: a batch that gets that much further still finishes inside the bound;
+    one that gets further yet is finished by the tail launch, correct and slower).  Until a first call has finished
+    every round is enqueued, as without it.  Keep lists do not depend on the bound; one object per call site and
+    stream."""
 
     UNKNOWN = 1 << 20
 
-    def __init__(self, margin=1):
-        self.margin = int(margin)
+    def __init__(self, slack=4):
+        self.slack = int(slack)
         self._used = {}
 
     def _slot(self, key, B):
@@ -530,7 +532,7 @@ class NmsRounds:
         """-> (max_rounds argument, pinned tensor the call reports into)."""
         t = self._slot(key, B)
         m = int(t.max())
-        return (0 if m >= self.UNKNOWN else m + self.margin), t
+        return (0 if m >= self.UNKNOWN else max(1, (m + self.slack + 15) // 16)), t
 
 
 def nms_sorted(boxes, n_per_image, iou_threshold, max_keep, rounds=None):

@@ -881,11 +881,16 @@ def test_nms_round_bound_never_changes_the_result(dev, oracle, max_rounds):
         ref = oracle.nms(boxes[i, :m], np.arange(m, 0, -1, dtype=np.float32), 0.7)[:P] if m else np.zeros((0,), np.int64)
         assert nk[i] == len(ref), (i, nk[i], len(ref))
         assert np.array_equal(keep[i, :nk[i]], ref)
+    # rounds_used counts 64-candidate blocks that had work (16 per round)
     total = (n + 1023) // 1024
-    assert used0[0] == 0 and used0[1] == 1 and used0[3] == total and 1 <= used0[2] < total and used0[4] <= 4
+    rounds0 = (used0 + 15) // 16
+    assert used0[0] == 0 and 1 <= used0[1] <= 11 and rounds0[3] == total and 1 <= rounds0[2] < total and rounds0[4] <= 4
     bound = max_rounds if max_rounds > 0 else total
-    for i in range(B):   # done within the bound: the true count; else the tail worked: all rounds
-        assert used[i] == (used0[i] if used0[i] <= bound else total), (i, used, used0)
+    for i in range(B):   # done within the bound: the same count; else the tail finished the image: the same rounds
+        if rounds0[i] <= bound:
+            assert used[i] == used0[i], (i, used, used0)
+        else:
+            assert used[i] > 16 * bound and (used[i] + 15) // 16 == rounds0[i], (i, used, used0)
 
 
 def test_nms_rounds_feed_forward(dev):
@@ -908,7 +913,7 @@ def test_nms_rounds_feed_forward(dev):
         assert torch.equal(nk, expect_ref[1])
         for b in range(B):
             assert torch.equal(keep[b, :int(nk[b])], expect_ref[0][b, :int(nk[b])])
-    assert 1 <= r.bound(key, B)[0] <= 5                 # after an easy batch: its rounds + 1
+    assert 1 <= r.bound(key, B)[0] <= 5                 # after an easy batch: the rounds that hold its blocks + slack
 
 
 def test_roi_pool_max_vs_oracle(dev, oracle):
