@@ -136,7 +136,7 @@ int frcnn_decode_clip_filter_nchw_f32(const float *anchors, int64_t anchor_batch
  * `stream`, their intermediates in one caller workspace of frcnn_rpn_proposals_workspace_bytes(B, A, k, max_keep)
  * bytes (contents on entry do not matter).  Same results as the four calls; one foreign call and no allocation per
  * step for the host.  Sizes: those frcnn_topk_desc_nchw_supported accepts (A > 8192, max_slices != 1).
- * props_out: (B, max_keep, 4), zero rows after n_keep_out[b]; max_rounds / rounds_used as in
+ * props_out: (B, max_keep, 4), zero rows after n_keep_out[b]; max_blocks / rounds_used as in
  * frcnn_nms_sorted_rounds_f32 (0 / NULL: every round). */
 size_t frcnn_rpn_proposals_workspace_bytes(int B, int A, int k, int max_keep);
 int frcnn_rpn_proposals_nchw_f32(const float *const *cls_host, const float *const *reg_host,
@@ -144,7 +144,7 @@ int frcnn_rpn_proposals_nchw_f32(const float *const *cls_host, const float *cons
                                  int64_t anchor_batch_stride, int B, int k, float image_h, float image_w,
                                  float min_size, double nms_threshold, int max_keep, float *props_out,
                                  int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
-                                 int max_slices, int max_rounds, int32_t *rounds_used, void *stream);
+                                 int max_slices, int max_blocks, int32_t *rounds_used, void *stream);
 
 /* ---- K4 NMS ----------------------------------------------------------------------------------
  * torchvision.ops.nms as called at RPN/rpn.py:84 and ROIHead/roi_head.py:215, batched.
@@ -164,18 +164,17 @@ int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, 
 /* frcnn_nms_sorted_f32 with a bound on the launches (same call sites, RPN/rpn.py:84 / ROIHead/roi_head.py:215;
  * the reference's per-image torchvision call has no such notion).  Above 2048 boxes NMS runs in rounds of 1024
  * candidates, two launches per round; rounds after max_keep is reached exit at once but are still launched,
- * because the host cannot know how many a batch needs (nine of twelve at 12,000 -> 2,000).  max_rounds > 0
- * enqueues at most that many rounds and then ONE tail launch that finishes any image that is not done, one
- * workgroup per image: slow when it has to work, and exact -- keep lists never depend on max_rounds
- * (max_rounds <= 0, or min(max_keep, max_n) > 2048: every round, no tail).  rounds_used: (B) int32, device or
- * host-mapped (pinned) memory, or NULL; written once, by the call's last launch: per image the 64-candidate BLOCKS
- * that had work to do (16 per round; how far into its last round an image got tells the caller how much slack a
- * bound has).  A caller feeds ceil((max(rounds_used) + slack) / 16) of one batch to the next call
- * (objectdetection_amd.ops.NmsRounds: slack = 4 blocks). */
+ * because the host cannot know how many a batch needs (nine of twelve at 12,000 -> 2,000).  max_blocks > 0: the
+ * rounds cover at most the first max_blocks 64-candidate blocks of every image (16 per round; the last round possibly
+ * only part of its candidates), then ONE tail launch finishes any image that is not done, one workgroup per image:
+ * slow when it has much to do, and exact -- keep lists never depend on max_blocks (max_blocks <= 0, or
+ * min(max_keep, max_n) > 2048: every round, no tail).  rounds_used: (B) int32, device or host-mapped (pinned) memory,
+ * or NULL; written once, by the call's last launch: per image the 64-candidate blocks that had work to do.  A caller
+ * feeds max(rounds_used) + slack of one batch to the next call (objectdetection_amd.ops.NmsRounds: slack = 4). */
 int frcnn_nms_sorted_rounds_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
                                 double iou_threshold, int max_keep, int32_t *keep_out,
                                 int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
-                                int max_rounds, int32_t *rounds_used, void *stream);
+                                int max_blocks, int32_t *rounds_used, void *stream);
 
 /* frcnn_nms_sorted_f32 for callers that cannot allocate device memory.  NO COUNTERPART IN THE REFERENCE: it
  * exists for callers under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc.  Same

@@ -328,13 +328,14 @@ __device__ __forceinline__ unsigned long long nms_tile_from_lds(const float4 *s_
 // Kernel PM of a round.  grid = (16 candidate blocks, RSPLIT pull slices + tile slices, B).
 __global__ void __launch_bounds__(256)
 nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
-                    int max_n, FrcnnThr thr, int max_keep, int cap, int round, int rsplit, char *ws,
+                    int max_n, int n_cap, FrcnnThr thr, int max_keep, int cap, int round, int rsplit, char *ws,
                     size_t ws_stride)
 {
     __shared__ float4 s_rows[4][64]; // a tile wave's row block
     __shared__ float s_rarea[4][64];
     const int b = blockIdx.z;
-    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
+    // (n_cap: the candidates this call's rounds cover; the tail launch takes the rest, see nms_sorted_run)
+    const int n = min(n_per_image ? min(n_per_image[b], max_n) : max_n, n_cap);
     const int base = round * NMS_RS;
     if (base >= n) return;
     const NmsWs w = nms_ws(ws, ws_stride, b, cap);
@@ -432,7 +433,7 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
 // survivors when few did (sparse: the handful of tiles is built here by the 16 waves).
 __global__ void __launch_bounds__(1024)
 nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
-                      int max_n, FrcnnThr thr, int max_keep, int cap, int round, char *ws,
+                      int max_n, int n_cap, FrcnnThr thr, int max_keep, int cap, int round, char *ws,
                       size_t ws_stride, int32_t *__restrict__ keep_out,
                       int32_t *__restrict__ n_keep_out, int32_t *rounds_used)
 {
@@ -442,9 +443,9 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     __shared__ int s_pos[NMS_RS];      // the list's positions inside the round
     __shared__ unsigned long long s_removed[NMS_RC];
     __shared__ unsigned long long s_K[NMS_RC];
-    __shared__ int s_nkeep, s_worked;
+    __shared__ int s_nkeep;
     const int b = blockIdx.x;
-    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
+    const int n = min(n_per_image ? min(n_per_image[b], max_n) : max_n, n_cap);
     const int base = round * NMS_RS;
     const NmsWs w = nms_ws(ws, ws_stride, b, cap);
     // Round 0 reads nothing of the workspace and leaves count, pull words and flag behind for the later rounds,
@@ -488,7 +489,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
     __syncthreads();
     int alive = 0;
     for (int c = 0; c < NMS_RC; ++c) alive += 64 - __popcll(s_removed[c]);
-    const bool dense = alive >= NMS_DENSE;
+    const bool dense = alive >= min(NMS_DENSE, (cnt + 1) / 2); // (a round cut short by the caller's bound: half of what it has)
     int count; // length of the list
     if (dense) {
         count = cnt;
@@ -543,11 +544,10 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
         unsigned long long removed[NMS_RC];
 #pragma unroll
         for (int cb = 0; cb < NMS_RC; ++cb) removed[cb] = uniform64(s_removed[cb]);
-        int nk = nk0, worked = 0;
+        int nk = nk0;
 #pragma unroll
         for (int c = 0; c < NMS_RC; ++c) {
             if (c < nC && nk < max_keep) {
-                worked = c + 1;
                 const int tb = nms_tile_id(c, c);
                 const unsigned long long col = s_tiles[tb * 64 + lane];
                 // the block's words in the later blocks' tiles: requested together, ahead of the resolve loop
@@ -580,10 +580,7 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
                 }
             }
         }
-        if (lane == 0) {
-            s_nkeep = nk;
-            s_worked = worked;
-        }
+        if (lane == 0) s_nkeep = nk;
     }
     __syncthreads();
     // append the round's keeps to the kept list (list order = candidate order)
@@ -602,10 +599,18 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
         *w.nkeep = s_nkeep;
         *w.dense = dense ? 1 : 0;
         // 64-candidate blocks that had work so far: where in the round max_keep was reached
-        int in_round = s_worked; // dense: the list is the round itself
-        if (!dense) {            // compacted list: where in the round its last examined entry stood
-            const int last = min(count, s_worked * 64) - 1;
-            in_round = last >= 0 ? s_pos[last] / 64 + 1 : NMS_RC;
+        // how far into the candidates this image's work reached: the block of the keep that filled max_keep, or --
+        // not filled yet -- every candidate of the round.  (A function of the data alone: the same whatever bound
+        // the call ran under, whether the list was the round itself or a compacted one.)
+        int in_round = (cnt + 63) >> 6;
+        if (s_nkeep >= max_keep) {
+            for (int c = NMS_RC - 1; c >= 0; --c) {
+                const unsigned long long K = s_K[c];
+                if (K != 0) {
+                    in_round = s_pos[c * 64 + 63 - __clzll((long long)K)] / 64 + 1;
+                    break;
+                }
+            }
         }
         const int blocks = round * NMS_RC + in_round;
         *w.rounds = blocks;
@@ -633,15 +638,15 @@ static FrcnnThr make_threshold(double thr)
     return th;
 }
 
-// max_rounds > 0: enqueue at most that many rounds of the round path, then ONE tail launch that finishes whatever
-// image is not done (nms_lazy_kernel's resume form) -- for callers who know from the previous batch how many rounds
-// do any work: rounds after max_keep is reached exit at once, but still cost two launches each (nine of twelve at
-// 12,000 -> 2,000).  The result never depends on max_rounds.  rounds_used (B ints, may be host-mapped memory, may
+// max_blocks > 0: the rounds cover at most the first max_blocks 64-candidate blocks of every image (the last round
+// possibly only part of its 16), then ONE tail launch finishes whatever image is not done (nms_lazy_kernel's resume
+// form) -- for callers who know from the previous batch how far into the candidates the work reaches: rounds after max_keep is reached exit at once, but still cost two launches each (nine of twelve at
+// 12,000 -> 2,000).  The result never depends on max_blocks.  rounds_used (B ints, may be host-mapped memory, may
 // be null): per image, the 64-candidate BLOCKS that had work (16 per round: how far into its last round an image
 // got tells the caller how much slack its bound has) -- written once, by the call's last launch.
 static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B, int max_n,
                           double iou_threshold, int max_keep, int32_t *keep_out, int32_t *n_keep_out,
-                          void *workspace, size_t workspace_bytes, int max_rounds, int32_t *rounds_used,
+                          void *workspace, size_t workspace_bytes, int max_blocks, int32_t *rounds_used,
                           void *stream)
 {
     FRCNN_REQUIRE(B >= 0 && max_n >= 0 && max_keep >= 0, "nms: bad shape");
@@ -681,24 +686,33 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
     }
     // the kept-list capacity of the workspace is max_n whatever max_keep is
     const size_t stride = nms_ws_stride(max_n);
-    const int rounds = (max_n + NMS_RS - 1) / NMS_RS;
     int rsplit = (NMS_PULL_WGS + NMS_RC * B - 1) / (NMS_RC * B); // pull slices: ~NMS_PULL_WGS workgroups in flight
     if (rsplit < 1) rsplit = 1;
     if (rsplit > 16) rsplit = 16;
-    // the tail keeps its kept list in LDS: only when that fits (RPN: 2,000 keeps) can rounds be left out
-    int run = rounds;
-    if (max_rounds > 0 && max_rounds < rounds && cap <= NMS_LAZY_MAX_N) run = max_rounds;
+    // the tail keeps its kept list in LDS: only when that fits (RPN: 2,000 keeps) can candidates be left to it
+    const int all_blocks = (max_n + 63) / 64;
+    int blocks = all_blocks;
+    if (max_blocks > 0 && max_blocks < all_blocks && cap <= NMS_LAZY_MAX_N) blocks = max_blocks;
+    const int run = (blocks + NMS_RC - 1) / NMS_RC; // rounds; the last one may cover only part of its candidates
+    const int n_cap = blocks < all_blocks ? blocks * 64 : max_n;
     for (int r = 0; r < run; ++r) {
-        hipLaunchKernelGGL(nms_round_pm_kernel, dim3(NMS_RC, rsplit + NMS_TILE_GROUPS, B), dim3(256), 0, st,
-                           (const float4 *)boxes, n_per_image, max_n, thr, max_keep, max_n, r, rsplit,
+        // a last round cut short has fewer candidate blocks: slice its pull finer, so that it still fills the chip
+        int rs = rsplit;
+        const int in_round = blocks - r * NMS_RC;
+        if (in_round < NMS_RC) {
+            rs = rsplit * NMS_RC / in_round;
+            if (rs > 16) rs = 16;
+        }
+        hipLaunchKernelGGL(nms_round_pm_kernel, dim3(NMS_RC, rs + NMS_TILE_GROUPS, B), dim3(256), 0, st,
+                           (const float4 *)boxes, n_per_image, max_n, n_cap, thr, max_keep, max_n, r, rs,
                            (char *)workspace, stride);
         FRCNN_CHECK_LAUNCH("nms_round_pm");
         hipLaunchKernelGGL(nms_round_scan_kernel, dim3(B), dim3(1024), 0, st, (const float4 *)boxes,
-                           n_per_image, max_n, thr, max_keep, max_n, r, (char *)workspace, stride,
-                           keep_out, n_keep_out, (run == rounds && r == rounds - 1) ? rounds_used : (int32_t *)nullptr);
+                           n_per_image, max_n, n_cap, thr, max_keep, max_n, r, (char *)workspace, stride,
+                           keep_out, n_keep_out, (blocks == all_blocks && r == run - 1) ? rounds_used : (int32_t *)nullptr);
         FRCNN_CHECK_LAUNCH("nms_round_scan");
     }
-    if (run < rounds) {
+    if (blocks < all_blocks) {
         const size_t lazy_lds = (size_t)cap * 24;
         if (lazy_lds > 48 * 1024) {
             static size_t granted[FRCNN_MAX_DEVICES];
@@ -707,7 +721,7 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
         }
         hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
                            (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out, n_keep_out,
-                           run * NMS_RC, (const char *)workspace, stride, max_n, rounds_used);
+                           blocks, (const char *)workspace, stride, max_n, rounds_used);
         FRCNN_CHECK_LAUNCH("nms_tail");
     }
     return FRCNN_OK;
@@ -725,10 +739,10 @@ extern "C" int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_ima
 extern "C" int frcnn_nms_sorted_rounds_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
                                            double iou_threshold, int max_keep, int32_t *keep_out,
                                            int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
-                                           int max_rounds, int32_t *rounds_used, void *stream)
+                                           int max_blocks, int32_t *rounds_used, void *stream)
 {
     return nms_sorted_run(boxes, n_per_image, B, max_n, iou_threshold, max_keep, keep_out, n_keep_out, workspace,
-                          workspace_bytes, max_rounds, rounds_used, stream);
+                          workspace_bytes, max_blocks, rounds_used, stream);
 }
 
 // ---- the entry point that allocates nothing ---------------------------------------------------------

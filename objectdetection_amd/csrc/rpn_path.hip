@@ -41,7 +41,7 @@ extern "C" int frcnn_rpn_proposals_nchw_f32(const float *const *cls_host, const 
                                             int64_t anchor_batch_stride, int B, int k, float image_h, float image_w,
                                             float min_size, double nms_threshold, int max_keep, float *props_out,
                                             int32_t *n_keep_out, void *workspace, size_t workspace_bytes,
-                                            int max_slices, int max_rounds, int32_t *rounds_used, void *stream)
+                                            int max_slices, int max_blocks, int32_t *rounds_used, void *stream)
 {
     FRCNN_REQUIRE(cls_host && reg_host && hw_host && anchors && B > 0 && k > 0 && max_keep > 0,
                   "rpn_proposals: bad arguments");
@@ -76,7 +76,7 @@ extern "C" int frcnn_rpn_proposals_nchw_f32(const float *const *cls_host, const 
                                            stream);                                                  // rpn.py:68-83
     if (rc != FRCNN_OK) return rc;
     rc = frcnn_nms_sorted_rounds_f32(boxes, count, B, k, nms_threshold, max_keep, keep, n_keep_out, base + w.nms,
-                                     w.total - w.nms, max_rounds, rounds_used, stream);              // rpn.py:84
+                                     w.total - w.nms, max_blocks, rounds_used, stream);              // rpn.py:84
     if (rc != FRCNN_OK) return rc;
     return frcnn_gather_boxes_f32(boxes, keep, n_keep_out, B, k, max_keep, props_out, stream);       // rpn.py:85
 }

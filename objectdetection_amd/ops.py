@@ -223,15 +223,15 @@ def rpn_proposals_nchw(list_cls, list_regs, anchors, k, image_h, image_w, min_si
         workspace = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
     props = torch.empty((B, max_keep, 4), dtype=torch.float32, device=dev)
     n_keep = torch.empty((B,), dtype=torch.int32, device=dev)
-    max_rounds, used = 0, None
+    max_blocks, used = 0, None
     if rounds is not None and lib.frcnn_nms_workspace_bytes(B, k) > 0:
-        max_rounds, used = rounds.bound((dev.index, B, k, max_keep, float(nms_threshold)), B)
+        max_blocks, used = rounds.bound((dev.index, B, k, max_keep, float(nms_threshold)), B)
     with torch.cuda.device(dev):
         rc = lib.frcnn_rpn_proposals_nchw_f32(
             ctypes.cast(ptrs_c, ctypes.c_void_p), ctypes.cast(ptrs_r, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p),
             len(ts_c), na, _ptr(anchors), stride, B, k, float(image_h), float(image_w), float(min_size),
             float(nms_threshold), max_keep, _ptr(props), _ptr(n_keep), _ptr(workspace), workspace.numel(),
-            int(max_slices), max_rounds, used.data_ptr() if used is not None else None, _stream())
+            int(max_slices), max_blocks, used.data_ptr() if used is not None else None, _stream())
     _lib.check(rc, "rpn_proposals_nchw")
     return props, n_keep, workspace
 
@@ -509,9 +509,9 @@ class NmsRounds:
     """How far into the round-path NMS the caller's recent batches got, fed forward as the next call's launch bound
     (frcnn_nms_sorted_rounds_f32).  The kernels leave, per image, the count of 64-candidate blocks that had work (16
     per round) in pinned host memory that the GPU writes directly; the host reads whatever has landed -- the counts
-    of the last call that FINISHED, never a synchronisation -- and asks for the rounds that hold their maximum plus
-    `slack` blocks (4 = a quarter of a round: a batch that gets that much further still finishes inside the bound;
-    one that gets further yet is finished by the tail launch, correct and slower).  Until a first call has finished
+    of the last call that FINISHED, never a synchronisation -- and asks for their maximum plus `slack` blocks (4 = a
+    quarter of a round: a batch that gets that much further still finishes inside the bound; one that gets further
+    yet is finished by the tail launch, correct and slower).  Until a first call has finished
     every round is enqueued, as without it.  Keep lists do not depend on the bound; one object per call site and
     stream."""
 
@@ -529,10 +529,10 @@ class NmsRounds:
         return t
 
     def bound(self, key, B):
-        """-> (max_rounds argument, pinned tensor the call reports into)."""
+        """-> (max_blocks argument, pinned tensor the call reports into)."""
         t = self._slot(key, B)
         m = int(t.max())
-        return (0 if m >= self.UNKNOWN else max(1, (m + self.slack + 15) // 16)), t
+        return (0 if m >= self.UNKNOWN else max(1, m + self.slack)), t
 
 
 def nms_sorted(boxes, n_per_image, iou_threshold, max_keep, rounds=None):
@@ -553,9 +553,9 @@ def nms_sorted(boxes, n_per_image, iou_threshold, max_keep, rounds=None):
         n_per_image = n_per_image.to(torch.int32)
     with torch.cuda.device(dev):
         if rounds is not None and nbytes > 0 and B > 0:
-            max_rounds, used = rounds.bound((dev.index, B, n, max_keep, float(iou_threshold)), B)
+            max_blocks, used = rounds.bound((dev.index, B, n, max_keep, float(iou_threshold)), B)
             rc = lib.frcnn_nms_sorted_rounds_f32(_ptr(boxes), _ptr(n_per_image), B, n, float(iou_threshold), max_keep,
-                                                 _ptr(keep), _ptr(n_keep), _ptr(ws), nbytes, max_rounds,
+                                                 _ptr(keep), _ptr(n_keep), _ptr(ws), nbytes, max_blocks,
                                                  used.data_ptr(), _stream())
         else:
             rc = lib.frcnn_nms_sorted_f32(_ptr(boxes), _ptr(n_per_image), B, n, float(iou_threshold), max_keep,
