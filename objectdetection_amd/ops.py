@@ -9,6 +9,7 @@ RPN/rpn.py:63,74,80,105; ROIHead/roi_head.py:99,178).
 Also exports `nms` and `MultiScaleRoIAlign` with torchvision's signatures, because the reference
 imports those two names (RPN/rpn.py:18, ROIHead/roi_head.py:26, ROIHead/roi_pooling.py:18).
 """
+import collections
 import ctypes
 import math
 
@@ -517,22 +518,30 @@ class NmsRounds:
 
     UNKNOWN = 1 << 20
 
-    def __init__(self, slack=4):
+    def __init__(self, slack=4, history=8):
         self.slack = int(slack)
+        self.history = int(history)
         self._used = {}
+        self._seen = {}
 
     def _slot(self, key, B):
         t = self._used.get(key)
         if t is None:
             t = torch.full((B,), self.UNKNOWN, dtype=torch.int32).pin_memory()
             self._used[key] = t
+            self._seen[key] = collections.deque(maxlen=self.history)
         return t
 
     def bound(self, key, B):
-        """-> (max_blocks argument, pinned tensor the call reports into)."""
+        """-> (max_blocks argument, pinned tensor the call reports into).  The bound covers the furthest any of the
+        last `history` observations got, plus the slack: batches whose reach wanders stay inside it."""
         t = self._slot(key, B)
         m = int(t.max())
-        return (0 if m >= self.UNKNOWN else max(1, m + self.slack)), t
+        if m >= self.UNKNOWN:
+            return 0, t
+        seen = self._seen[key]
+        seen.append(m)
+        return max(1, max(seen) + self.slack), t
 
 
 def nms_sorted(boxes, n_per_image, iou_threshold, max_keep, rounds=None):
