@@ -672,7 +672,7 @@ def next_rows_microbench(dev):
     nbytes = B * Pn * C * 49 * 4 + B * C * FH * FW * 4
     res["roi_align_backward_B16_K2000_C512"] = {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / ms / 1e6,
                                                 "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS,
-                                                "kernel": "roi_align_plane_backward_kernel (LDS float atomics)"}
+                                                "kernel": "roi_align_plane_backward_kernel (MFMA form: Wy^T (G Wx) per RoI into LDS-resident planes, no atomics)"}
     del gout, feat
     # row 4: decode backward on the batch's 16 x 12,000 candidates
     n = B * PRE_NMS

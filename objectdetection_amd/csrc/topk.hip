@@ -1080,10 +1080,12 @@ extern "C" size_t frcnn_topk_workspace_bytes(int B, int n, int k)
     // enough for every plan frcnn_topk_desc_ex_f32 can choose: one workgroup per image needs 4 n or 4 k words,
     // the split path 4 n for the slice sorts plus the slices' lists (keys and indices, at most n rounded up
     // to whole wave rounds per slice)
-    // (+ the selective variant's per-slice histograms, list lengths and threshold)
-    if (n > 8 * TOPK_THREADS)
-        return (size_t)B * (6 * (size_t)n + 2 * 64 * TOPK_MAX_SLICES + (size_t)TOPK_MAX_SLICES * (TOPK_SEL_BINS + 1) + 64) *
-                   sizeof(uint32_t) + 16;
+    // (+ the selective variant's per-slice histograms, list lengths and threshold, where it applies: k <= n / 4)
+    if (n > 8 * TOPK_THREADS) {
+        size_t words = 6 * (size_t)n + 2 * 64 * TOPK_MAX_SLICES;
+        if (4LL * k <= n) words += (size_t)TOPK_MAX_SLICES * (TOPK_SEL_BINS + 1) + 64;
+        return (size_t)B * words * sizeof(uint32_t) + 16;
+    }
     const size_t per = topk_use_sort(n, k) ? (size_t)n : (size_t)k;
     return (size_t)B * 4 * per * sizeof(uint32_t);
 }
