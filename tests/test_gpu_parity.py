@@ -1,11 +1,13 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
 vectors.  Bit-exact for anchors, IoU, labels, argmax, top-k order, filter indices, NMS keep lists,
 level indices and RoI-pool argmax; 1e-5 relative for exp/log/bilinear outputs."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from tests.conftest import load_golden
+from tests.conftest import ROOT, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -1657,3 +1659,19 @@ def test_roi_head_training_sends_gradients_to_the_feature_maps(dev):
     with torch.no_grad():
         out = head.roi_pooling({'1': feats[0], '2': feats[1]}, props, [(256, 256)])
     assert not out.requires_grad
+
+
+def test_randomised_shapes_against_the_oracle(dev, oracle):
+    """A fixed slice of tools/fuzz_parity.py's draws (shapes, counts, data kinds and bounds drawn at random rather
+    than chosen): every op of the path, 20 draws each.  The tool itself runs the same draws for minutes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    for name, fn in fz.OPS.items():
+        for i in range(20):
+            seed = 424243 + 1000 * i + len(name)
+            try:
+                fn(np.random.default_rng(seed))
+            except AssertionError as e:
+                raise AssertionError(f"{name}, seed {seed}: {e}") from e
