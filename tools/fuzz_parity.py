@@ -243,7 +243,39 @@ def fuzz_rpn(rng):
     return f"info={info} levels={fsz} pre={pre} post={post} thr={thr} min={min_size}"
 
 
-OPS = {"rpn": fuzz_rpn, "topk": fuzz_topk, "nms": fuzz_nms, "roi_align": fuzz_roi_align, "roi_backward": fuzz_roi_backward,
+def fuzz_targets(rng):
+    """IoU matrix + threshold labels + argmax + delta encodings (utils.box_iou / tagging_box / box_deviation fused):
+    shared or per-image box_1, ragged box counts, duplicates and exact hits, both threshold pairs of the reference."""
+    B = int(rng.integers(1, 6))
+    A = size(rng, 30000, 2000)
+    M = int(rng.choice([1, 2, 37, 100, int(rng.integers(1, 130))]))
+    ms = [int(rng.choice([1, M, int(rng.integers(1, M + 1))])) for _ in range(B)]
+    per_image = rng.random() < 0.5
+    box1 = np.stack([realistic_boxes(rng, A) for _ in range(B)]) if per_image else realistic_boxes(rng, A)
+    w = rng.uniform(8, 300, (B, M)); h = rng.uniform(8, 300, (B, M))
+    x1 = rng.uniform(0, 1000 - w); y1 = rng.uniform(0, 600 - h)
+    gt = np.stack([x1, y1, x1 + w, y1 + h], 2).astype(np.float32)
+    if M > 1:
+        gt[:, 1] = gt[:, 0]   # a duplicate box: first-max argmax
+    for b in range(B):        # exact hits and near hits: IoU = 1 and around the thresholds
+        src = box1[b] if per_image else box1
+        j = rng.integers(0, A, min(A, 3 * ms[b]))
+        src[j] = gt[b, rng.integers(0, ms[b], len(j))] + (rng.normal(0, 4, (len(j), 4)) * (rng.random((len(j), 1)) < 0.7)).astype(np.float32)
+    lab = rng.integers(1, 21, (B, M)).astype(np.float32)
+    neg, pos = (0.3, 0.7) if rng.random() < 0.5 else (0.5, 0.5)
+    out = ops.iou_label_encode(T(box1, dev), T(gt, dev), T(np.asarray(ms, np.int32), dev, torch.int32), neg, pos,
+                               T(lab, dev), [10.0, 10.0, 5.0, 5.0])
+    for b in range(B):
+        l, a, mx, dv = orc.iou_label_encode(box1[b] if per_image else box1, gt[b, :ms[b]], neg, pos, lab[b, :ms[b]],
+                                            [10.0, 10.0, 5.0, 5.0])
+        assert_bits_equal(out["label"][b].cpu().numpy(), l)
+        assert np.array_equal(out["argmax"][b].cpu().numpy(), a), f"image {b}: argmax differs"
+        assert_bits_equal(out["max_iou"][b].cpu().numpy(), mx)
+        np.testing.assert_allclose(out["dev"][b].cpu().numpy(), dv, rtol=RTOL, atol=1e-6)
+    return f"B={B} A={A} M={M} ms={ms} per_image={per_image} thr=({neg},{pos})"
+
+
+OPS = {"targets": fuzz_targets, "rpn": fuzz_rpn, "topk": fuzz_topk, "nms": fuzz_nms, "roi_align": fuzz_roi_align, "roi_backward": fuzz_roi_backward,
        "roi_pool": fuzz_roi_pool}
 
 
