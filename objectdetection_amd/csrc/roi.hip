@@ -561,13 +561,25 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
     __shared__ float4 s_rec[RAW_LIST];
     __shared__ int s_idx[RAW_LIST];
     __shared__ int s_off, s_cnt, s_n;
-    // block order as in roi_align_plane_kernel: the channel splits of one (window, image) share an XCD
-    const int slot = blockIdx.x >> 3;
+    // Block order.  Blocks i and i + 8 share an XCD (and its L2), and windows overlap by half: an XCD is given
+    // whole IMAGES (batches of 8 or more) or whole window rows of an image, neighbouring windows in consecutive
+    // blocks, so that a pixel staged for one window is still in that L2 when the next window asks for it --
+    // the 4x re-read of the maps then stays on the XCD instead of crossing the fabric.  The channel splits of
+    // a (window, image) are consecutive too (they share the output lines of their RoIs).
+    const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7;
     const int cs = slot % csplit;
-    const int grp = (slot / csplit) * 8 + (blockIdx.x & 7); // (window, image); padded to a multiple of 8
-    if (grp >= nwy * nwx * B) return;
-    const int wid = grp % (nwy * nwx);
-    const int b = grp / (nwy * nwx);
+    const int r = slot / csplit;
+    int b, wid;
+    if (B >= 8) {
+        wid = r % (nwy * nwx);
+        b = (r / (nwy * nwx)) * 8 + xcd;
+        if (b >= B) return;
+    } else {
+        const int u = (r / nwx) * 8 + xcd; // (image, window row)
+        if (u >= B * nwy) return;
+        b = u / nwy;
+        wid = (u % nwy) * nwx + r % nwx;
+    }
     const int chunks = (C + 4 * RAW_G - 1) / (4 * RAW_G);
     const int HW = H * W;
     const int wy0 = (wid / nwx) * RAW_STEP, wx0 = (wid % nwx) * RAW_STEP;
@@ -582,7 +594,7 @@ roi_align_window_kernel(const float *__restrict__ feat, int C, int H, int W,
         }
         s_off = off;
         s_n = 0;
-        if (total_out && cs == 0 && grp == 0) *total_out = tot;
+        if (total_out && cs == 0 && b == 0 && wid == 0) *total_out = tot;
     }
     __syncthreads();
     const int cnt = s_cnt;
@@ -875,7 +887,9 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
                 FRCNN_REQUIRE(e == hipSuccess, "roi_align_batched: cannot reserve %zu B of LDS: %s", lds,
                               hipGetErrorString(e));
             }
-            const long long groups8 = ((long long)nwy * nwx * B + 7) / 8 * 8;
+            // (the kernel's block order: whole images per XCD from 8 images on, else whole window rows)
+            const long long units = B >= 8 ? B : (long long)B * nwy, per_unit = B >= 8 ? (long long)nwy * nwx : nwx;
+            const long long groups8 = (units + 7) / 8 * per_unit * 8;
             FRCNN_REQUIRE(groups8 * chunks16 < (1ll << 31), "roi_align_batched: grid too large");
             const dim3 grid((unsigned)(groups8 * chunks16));
             if (full)
