@@ -1675,3 +1675,34 @@ def test_randomised_shapes_against_the_oracle(dev, oracle):
                 fn(np.random.default_rng(seed))
             except AssertionError as e:
                 raise AssertionError(f"{name}, seed {seed}: {e}") from e
+
+
+@pytest.mark.parametrize("B", [8, 11, 17])
+def test_roi_align_window_kernel_whole_images_per_xcd(dev, oracle, B):
+    """Batches of 8 images or more: the window kernel hands whole images to an XCD (below that whole window rows).
+    Image counts that are and are not multiples of 8, ragged RoI counts, an image without RoIs."""
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    rng = np.random.default_rng(800 + B)
+    C, H, W, stride = 12, 100, 168, 8
+    Himg, Wimg = H * stride, W * stride
+    feat = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    counts = [int(rng.integers(1, 60)) for _ in range(B)]
+    counts[B // 2] = 0
+    props = []
+    for n in counts:
+        s = rng.uniform(8, 240, (n, 2))
+        c = rng.uniform(0, 1, (n, 2)) * [Wimg, Himg]
+        bx = np.concatenate([c - s / 2, c + s / 2], 1)
+        bx[:, 0::2] = bx[:, 0::2].clip(0, Wimg)
+        bx[:, 1::2] = bx[:, 1::2].clip(0, Himg)
+        props.append(bx.astype(np.float32))
+    ref, _ = oracle.multiscale_roi_align([feat], props, [(Himg, Wimg)], (7, 7), 2)
+    P = max(counts)
+    padded = np.zeros((B, P, 4), np.float32)
+    for b, p in enumerate(props):
+        padded[b, :len(p)] = p
+    pool = ROIPooling(['1'], [7, 7], 2)
+    out, total = pool.forward_padded({'1': T(feat, dev)}, T(padded, dev), T(np.asarray(counts, np.int32), dev, torch.int32),
+                                     [(Himg, Wimg)])
+    assert int(total) == sum(counts)
+    np.testing.assert_allclose(out[:sum(counts)].cpu().numpy(), ref, rtol=RTOL, atol=1e-5)
