@@ -697,9 +697,9 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
     const int n_cap = blocks < all_blocks ? blocks * 64 : max_n;
     for (int r = 0; r < run; ++r) {
         // a last round cut short has fewer candidate blocks: slice its pull finer, so that it still fills the chip
-        int rs = rsplit;
+        int rs = r == 0 ? 0 : rsplit; // (round 0 has no kept boxes to pull against: tile slices only)
         const int in_round = blocks - r * NMS_RC;
-        if (in_round < NMS_RC) {
+        if (in_round < NMS_RC && r > 0) {
             rs = rsplit * NMS_RC / in_round;
             if (rs > 16) rs = 16;
         }
