@@ -34,6 +34,8 @@ A = FH * FW * NA
 PRE_NMS, POST_NMS, NMS_THR, MIN_SIZE = 12000, 2000, 0.7, 1e-3
 SETTLE_STEPS = 40
 TOPK_SLICES_PIPELINED = int(os.environ.get("BENCH_TOPK_SLICES", "1"))
+PIPE_ONE_CALL = int(os.environ.get('BENCH_PIPE_ONE_CALL', '1'))
+PIPE_ONE_CALL_SLICES = int(os.environ.get('BENCH_PIPE_SLICES', '0'))
 
 
 _ANCHOR_WH = None
@@ -107,6 +109,7 @@ class Path:
         # workload, before any has finished, enqueue every round)
         self.nms_rounds = ops.NmsRounds()
         self.path_ws = None
+        self.pipe_ws = None
         self.dev = dev
         self.ag = AnchorGenerator()
         self.pool = ROIPooling(['1'], [7, 7], 2)
@@ -177,6 +180,15 @@ class Path:
 
         def proposals():
             mark("start", pipe.s_prop)
+            if self.in_place and (ev is None or only_roi) and PIPE_ONE_CALL:
+                # the proposal half as ONE library call on the proposal stream (its workspace is reused by the next
+                # batch's call on the same stream: calls on one stream run in order)
+                props, n_keep, self.pipe_ws = ops.rpn_proposals_nchw([cls], [reg], anchors, PRE_NMS, IMG_H, IMG_W,
+                                                                     MIN_SIZE, NMS_THR, POST_NMS,
+                                                                     max_slices=PIPE_ONE_CALL_SLICES,
+                                                                     rounds=self.nms_rounds, workspace=self.pipe_ws)
+                mark("gather", pipe.s_prop)
+                return props, n_keep
             scores, deltas = ops.rpn_flatten([cls], [reg])
             mark("flatten", pipe.s_prop)
             # one workgroup per image: beside RoIAlign every slice workgroup would wait for a CU of its own
