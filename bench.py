@@ -34,7 +34,8 @@ A = FH * FW * NA
 PRE_NMS, POST_NMS, NMS_THR, MIN_SIZE = 12000, 2000, 0.7, 1e-3
 SETTLE_STEPS = 40
 TOPK_SLICES_PIPELINED = int(os.environ.get("BENCH_TOPK_SLICES", "1"))
-PIPE_ONE_CALL = int(os.environ.get('BENCH_PIPE_ONE_CALL', '1'))
+# (experimental, see DESIGN.md section 5: +2 % as the run's main schedule, unstable as the second schedule of a process)
+PIPE_ONE_CALL = int(os.environ.get('BENCH_PIPE_ONE_CALL', '0'))
 PIPE_ONE_CALL_SLICES = int(os.environ.get('BENCH_PIPE_SLICES', '0'))
 
 
@@ -338,6 +339,12 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
+    if os.environ.get("BENCH_DEBUG"):
+        st = torch.cuda.memory_stats()
+        print("BENCH_DEBUG run", workload, "B", B, "steps", steps, "pipelined", pipelined, "ms/step %.3f" % ms_per_step,
+              "segments +%s -%s" % (st.get("segment.all.allocated"), st.get("segment.all.freed")),
+              "reserved %.1f GB" % (st.get("reserved_bytes.all.current", 0) / 1e9),
+              {k: list(v) for k, v in path.nms_rounds._seen.items()}, file=sys.stderr, flush=True)
     res = dict(workload=workload, value=world * B * steps / elapsed, ms_per_step=ms_per_step, stage_ms=stage_ms,
                roi_queue_wait_ms=queue_wait,
                proposals_per_image_mean=float(np.mean(counts)), rois_per_step=n_rois,

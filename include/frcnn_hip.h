@@ -166,8 +166,8 @@ int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, 
  * candidates, two launches per round; rounds after max_keep is reached exit at once but are still launched,
  * because the host cannot know how many a batch needs (nine of twelve at 12,000 -> 2,000).  max_blocks > 0: the
  * rounds cover at most the first max_blocks 64-candidate blocks of every image (16 per round; the last round possibly
- * only part of its candidates), then ONE tail launch finishes any image that is not done, one workgroup per image:
- * slow when it has much to do, and exact -- keep lists never depend on max_blocks (max_blocks <= 0, or
+ * only part of its candidates), and the last round's one-workgroup-per-image launch finishes any image that is still
+ * not done by itself, 64 candidates at a time: slow when it has much to do, and exact -- keep lists never depend on max_blocks (max_blocks <= 0, or
  * min(max_keep, max_n) > 2048: every round, no tail).  rounds_used: (B) int32, device or host-mapped (pinned) memory,
  * or NULL; written once, by the call's last launch: per image the 64-candidate blocks that had work to do.  A caller
  * feeds max(rounds_used) + slack of one batch to the next call (objectdetection_amd.ops.NmsRounds: slack = 4). */

@@ -55,6 +55,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
 // part of the IoU matrix that greedy NMS actually consults is ever evaluated (a few million pairs
 // instead of n^2/2 = 72 M at n = 12,000).  Same fp32 IoU expression, same threshold rule.
 #define NMS_LAZY_THREADS 1024
+#define NMS_LAZY_MAX_N 2048 // candidates (and so keeps) whose kept list fits LDS: 24 B per keep
 #define NMS_LAZY_WAVES 16
 #define NMS_RT_BYTES (136 * 64 * 8) // one round's tiles in the round path's workspace (NMS_RT * 64 words, below)
 
@@ -63,49 +64,18 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane)
     return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src_lane));
 }
 
-__global__ void __launch_bounds__(NMS_LAZY_THREADS)
-nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image, int max_n,
-                FrcnnThr thr, int max_keep, int cap, int32_t *__restrict__ keep_out,
-                int32_t *__restrict__ n_keep_out, int first_block, const char *resume_ws, size_t resume_stride,
-                int resume_cap, int32_t *rounds_used)
+// The walk of nms_lazy_kernel: candidates from block `first_block` on, 64 at a time, against the kept list in LDS (nk0
+// entries on entry; the keeps found are appended: boxes, areas, positions).  Every thread of a 1024-thread workgroup
+// calls it (it contains barriers).  Returns the number of keeps; *blocks_out = blocks that had work.
+__device__ __forceinline__ int nms_lazy_walk(const float4 *__restrict__ bx, int n, int first_block, int nk0,
+                                             const FrcnnThr &thr, int max_keep, float4 *s_kbox, float *s_karea,
+                                             int *s_kidx, float4 *s_cand, unsigned long long *s_row, unsigned *s_rem,
+                                             int *s_nkeep_p, int *blocks_out)
 {
-    // dynamic LDS: [cap] kept boxes (float4), [cap] kept areas, [cap] kept positions
-    extern __shared__ float4 s_kbox[];
-    float *s_karea = (float *)(s_kbox + cap);
-    int *s_kidx = (int *)(s_karea + cap);
-    __shared__ float4 s_cand[NMS_LAZY_THREADS]; // the next 16 blocks of candidates, staged per refill
-    __shared__ unsigned long long s_row[64];
-    __shared__ unsigned s_rem[2];
-    __shared__ int s_nkeep;
-    const int b = blockIdx.x;
-    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
+    int &s_nkeep = *s_nkeep_p;
     const int Wn = (n + 63) >> 6;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const float4 *bx = boxes + (long long)b * max_n;
-    // Resume form (the round path's tail, see nms_sorted_run): the image's state is what the rounds before
-    // `first_block` left in the workspace.  Nothing to do -- the normal case -- when they reached max_keep or the
-    // end of the candidates; otherwise the kept list is fetched into LDS and the candidates from first_block on
-    // are worked off here, one workgroup per image (slow next to the rounds, and exact all the same).
-    int nk0 = 0;
-    if (resume_ws) {
-        const char *p = resume_ws + (size_t)b * resume_stride;
-        const float4 *kbox = (const float4 *)p;
-        p += ((size_t)resume_cap * 16 + 255) / 256 * 256;
-        const float *karea = (const float *)p;
-        p += ((size_t)resume_cap * 4 + 255) / 256 * 256 + (size_t)NMS_RT_BYTES + 256;
-        const int *state = (const int *)p; // nkeep, dense, rounds
-        nk0 = state[0];
-        const bool idle = first_block * 64 >= n || nk0 >= max_keep;
-        if (idle) {
-            if (threadIdx.x == 0 && rounds_used) rounds_used[b] = state[2];
-            return;
-        }
-        for (int t = threadIdx.x; t < nk0; t += NMS_LAZY_THREADS) {
-            s_kbox[t] = kbox[t];
-            s_karea[t] = karea[t];
-        }
-    }
     if (threadIdx.x == 0) {
         s_nkeep = nk0;
         s_rem[0] = 0;
@@ -207,12 +177,31 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
     }
     __syncthreads();
     nkeep_final = s_nkeep;
+    *blocks_out = blocks_done;
+    return nkeep_final;
+}
+
+__global__ void __launch_bounds__(NMS_LAZY_THREADS)
+nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image, int max_n,
+                FrcnnThr thr, int max_keep, int cap, int32_t *__restrict__ keep_out,
+                int32_t *__restrict__ n_keep_out)
+{
+    // dynamic LDS: [cap] kept boxes (float4), [cap] kept areas, [cap] kept positions
+    extern __shared__ float4 s_kbox[];
+    float *s_karea = (float *)(s_kbox + cap);
+    int *s_kidx = (int *)(s_karea + cap);
+    __shared__ float4 s_cand[NMS_LAZY_THREADS]; // the next 16 blocks of candidates, staged per refill
+    __shared__ unsigned long long s_row[64];
+    __shared__ unsigned s_rem[2];
+    __shared__ int s_nkeep;
+    const int b = blockIdx.x;
+    const int n = n_per_image ? min(n_per_image[b], max_n) : max_n;
+    int blocks_done = 0;
+    const int nkeep_final = nms_lazy_walk(boxes + (long long)b * max_n, n, 0, 0, thr, max_keep, s_kbox, s_karea, s_kidx,
+                                          s_cand, s_row, s_rem, &s_nkeep, &blocks_done);
     int32_t *keep = keep_out + (long long)b * max_keep;
-    for (int t = nk0 + threadIdx.x; t < nkeep_final; t += NMS_LAZY_THREADS) keep[t] = s_kidx[t];
-    if (threadIdx.x == 0) {
-        n_keep_out[b] = nkeep_final;
-        if (resume_ws && rounds_used) rounds_used[b] = blocks_done;
-    }
+    for (int t = threadIdx.x; t < nkeep_final; t += NMS_LAZY_THREADS) keep[t] = s_kidx[t];
+    if (threadIdx.x == 0) n_keep_out[b] = nkeep_final;
 }
 
 // ---- round-based NMS --------------------------------------------------------------------------
@@ -225,6 +214,7 @@ nms_lazy_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_
 #define NMS_DENSE 512                     // survivors per round from which chip-wide tiles pay off
 #define NMS_TILE_WORDS ((NMS_RT * 64 + 1023) / 1024) // tile words per thread of the scan kernel (9)
 static_assert(NMS_RT_BYTES == NMS_RT * 64 * 8, "NMS_RT_BYTES");
+static_assert(NMS_RT_BYTES >= NMS_LAZY_MAX_N * 24 && NMS_RS == NMS_LAZY_THREADS, "the tail walk's kept list (NMS_LAZY_MAX_N entries) lies over the scan kernel's tiles, its candidates over the list");
 #define NMS_TILE_GROUPS ((NMS_RT + NMS_RC * 4 - 1) / (NMS_RC * 4)) // grid.y slices of tile waves (3)
 
 // Per-image workspace of the round path (all offsets 16-byte aligned).
@@ -334,7 +324,7 @@ nms_round_pm_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict_
     __shared__ float4 s_rows[4][64]; // a tile wave's row block
     __shared__ float s_rarea[4][64];
     const int b = blockIdx.z;
-    // (n_cap: the candidates this call's rounds cover; the tail launch takes the rest, see nms_sorted_run)
+    // (n_cap: the candidates this call's rounds cover; the last scan's tail takes the rest, see nms_sorted_run)
     const int n = min(n_per_image ? min(n_per_image[b], max_n) : max_n, n_cap);
     const int base = round * NMS_RS;
     if (base >= n) return;
@@ -435,9 +425,11 @@ __global__ void __launch_bounds__(1024)
 nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_per_image,
                       int max_n, int n_cap, FrcnnThr thr, int max_keep, int cap, int round, char *ws,
                       size_t ws_stride, int32_t *__restrict__ keep_out,
-                      int32_t *__restrict__ n_keep_out, int32_t *rounds_used)
+                      int32_t *__restrict__ n_keep_out, int32_t *rounds_used, int tail_block)
 {
     __shared__ unsigned long long s_tiles[NMS_RT * 64];
+    __shared__ unsigned long long s_trow[64]; // the tail walk's (tail_block > 0)
+    __shared__ unsigned s_trem[2];
     __shared__ float4 s_box[NMS_RS];   // the list's boxes
     __shared__ float s_area[NMS_RS];   // and their areas
     __shared__ int s_pos[NMS_RS];      // the list's positions inside the round
@@ -593,6 +585,10 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
             w.kbox[pos] = bxv;
             w.karea[pos] = s_area[t];
             keep_out[(long long)b * max_keep + pos] = base + s_pos[t];
+            if (tail_block > 0 && pos < NMS_LAZY_MAX_N) { // (the tiles are done with: the tail's kept list lies over them)
+                ((float4 *)s_tiles)[pos] = bxv;
+                ((float *)((float4 *)s_tiles + NMS_LAZY_MAX_N))[pos] = s_area[t];
+            }
         }
     }
     if (t == 0) {
@@ -617,9 +613,35 @@ nms_round_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restric
         n_keep_out[b] = s_nkeep;
         if (rounds_used) rounds_used[b] = blocks;
     }
+    // The call's last round under a bound (tail_block = the first 64-candidate block the rounds did not cover): an
+    // image that is neither full nor out of candidates -- the bound was too tight for it -- is finished here, by this
+    // workgroup, 64 candidates at a time against its kept list in LDS (nms_lazy_walk: slow next to the rounds, exact all
+    // the same).  The normal case costs the test.  Kept list: the earlier rounds' entries from the workspace, this round's
+    // were put into LDS as they were appended.
+    if (tail_block > 0) {
+        const int n_img = n_per_image ? min(n_per_image[b], max_n) : max_n;
+        __syncthreads();
+        const int nk1 = s_nkeep;
+        if (nk1 < max_keep && tail_block * 64 < n_img) {
+            float4 *l_kbox = (float4 *)s_tiles;
+            float *l_karea = (float *)(l_kbox + NMS_LAZY_MAX_N);
+            int *l_kidx = (int *)(l_karea + NMS_LAZY_MAX_N);
+            for (int i = t; i < nk0; i += 1024) {
+                l_kbox[i] = w.kbox[i];
+                l_karea[i] = w.karea[i];
+            }
+            int blocks_done = tail_block;
+            const int nk2 = nms_lazy_walk(boxes + (long long)b * max_n, n_img, tail_block, nk1, thr, max_keep, l_kbox,
+                                          l_karea, l_kidx, s_box, s_trow, s_trem, &s_nkeep, &blocks_done);
+            for (int i = nk1 + t; i < nk2; i += 1024) keep_out[(long long)b * max_keep + i] = l_kidx[i];
+            if (t == 0) {
+                n_keep_out[b] = nk2;
+                if (rounds_used) rounds_used[b] = blocks_done;
+            }
+        }
+    }
 }
 
-#define NMS_LAZY_MAX_N 2048
 
 extern "C" size_t frcnn_nms_workspace_bytes(int B, int max_n)
 {
@@ -639,8 +661,8 @@ static FrcnnThr make_threshold(double thr)
 }
 
 // max_blocks > 0: the rounds cover at most the first max_blocks 64-candidate blocks of every image (the last round
-// possibly only part of its 16), then ONE tail launch finishes whatever image is not done (nms_lazy_kernel's resume
-// form) -- for callers who know from the previous batch how far into the candidates the work reaches: rounds after max_keep is reached exit at once, but still cost two launches each (nine of twelve at
+// possibly only part of its 16), and the last round's scan workgroup finishes whatever image is not done by itself
+// (nms_lazy_walk, the tail) -- for callers who know from the previous batch how far into the candidates the work reaches: rounds after max_keep is reached exit at once, but still cost two launches each (nine of twelve at
 // 12,000 -> 2,000).  The result never depends on max_blocks.  rounds_used (B ints, may be host-mapped memory, may
 // be null): per image, the 64-candidate BLOCKS that had work (16 per round: how far into its last round an image
 // got tells the caller how much slack its bound has) -- written once, by the call's last launch.
@@ -672,8 +694,7 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
             FRCNN_REQUIRE(e == hipSuccess, "nms: cannot reserve LDS: %s", hipGetErrorString(e));
         }
         hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
-                           (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out,
-                           n_keep_out, 0, (const char *)nullptr, (size_t)0, 0, (int32_t *)nullptr);
+                           (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out, n_keep_out);
         FRCNN_CHECK_LAUNCH("nms_lazy");
         return FRCNN_OK;
     }
@@ -709,20 +730,9 @@ static int nms_sorted_run(const float *boxes, const int32_t *n_per_image, int B,
         FRCNN_CHECK_LAUNCH("nms_round_pm");
         hipLaunchKernelGGL(nms_round_scan_kernel, dim3(B), dim3(1024), 0, st, (const float4 *)boxes,
                            n_per_image, max_n, n_cap, thr, max_keep, max_n, r, (char *)workspace, stride,
-                           keep_out, n_keep_out, (blocks == all_blocks && r == run - 1) ? rounds_used : (int32_t *)nullptr);
+                           keep_out, n_keep_out, r == run - 1 ? rounds_used : (int32_t *)nullptr,
+                           (r == run - 1 && blocks < all_blocks) ? blocks : 0);
         FRCNN_CHECK_LAUNCH("nms_round_scan");
-    }
-    if (blocks < all_blocks) {
-        const size_t lazy_lds = (size_t)cap * 24;
-        if (lazy_lds > 48 * 1024) {
-            static size_t granted[FRCNN_MAX_DEVICES];
-            hipError_t e = frcnn_reserve_dynamic_lds((const void *)nms_lazy_kernel, NMS_LAZY_MAX_N * 24, granted);
-            FRCNN_REQUIRE(e == hipSuccess, "nms: cannot reserve LDS: %s", hipGetErrorString(e));
-        }
-        hipLaunchKernelGGL(nms_lazy_kernel, dim3(B), dim3(NMS_LAZY_THREADS), lazy_lds, st,
-                           (const float4 *)boxes, n_per_image, max_n, thr, max_keep, cap, keep_out, n_keep_out,
-                           blocks, (const char *)workspace, stride, max_n, rounds_used);
-        FRCNN_CHECK_LAUNCH("nms_tail");
     }
     return FRCNN_OK;
 }

@@ -512,7 +512,7 @@ class NmsRounds:
     per round) in pinned host memory that the GPU writes directly; the host reads whatever has landed -- the counts
     of the last call that FINISHED, never a synchronisation -- and asks for their maximum plus `slack` blocks (4 = a
     quarter of a round: a batch that gets that much further still finishes inside the bound; one that gets further
-    yet is finished by the tail launch, correct and slower).  Until a first call has finished
+    yet is finished by the last round's tail, correct and slower).  Until a first call has finished
     every round is enqueued, as without it.  Keep lists do not depend on the bound; one object per call site and
     stream."""
 

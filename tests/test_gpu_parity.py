@@ -845,7 +845,7 @@ def test_nms_workspace_needs_no_clearing(dev, oracle):
 @pytest.mark.parametrize("max_blocks", [1, 16, 20, 37, 80, 0])
 def test_nms_round_bound_never_changes_the_result(dev, oracle, max_blocks):
     """frcnn_nms_sorted_rounds_f32 through the C ABI: with the rounds covering fewer 64-candidate blocks than the
-    batch needs (whole rounds, or a last round cut short), the tail launch finishes the images that are not done
+    batch needs (whole rounds, or a last round cut short), the last round's tail finishes the images that are not done
     and the keep lists are those of the unbounded call (and of the oracle).  Images: empty, one round, max_keep reached in round 2, all 6 rounds needed (sparse boxes, few keeps),
     ragged.  rounds_used (pinned host memory the kernels write directly) = rounds that had work, or all of them
     for an image the tail had to finish."""
