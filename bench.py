@@ -168,6 +168,16 @@ class Path:
         mark("roi_align")
         return props, n_keep, out, total
 
+    def _pipe_rounds(self):
+        mode = os.environ.get("BENCH_PIPE_ROUNDS", "shared")
+        if mode == "none":
+            return None
+        if mode == "own":
+            if not hasattr(self, "_own_rounds"):
+                self._own_rounds = self.ops.NmsRounds()
+            return self._own_rounds
+        return self.nms_rounds
+
     def step_pipelined(self, anchors, cls, reg, feat, ev=None, only_roi=False):
         """Same work as step(); proposal stages and RoIAlign on the two streams of ProposalRoIPipeline,
         so that consecutive steps overlap (software pipeline of depth 2 over batches)."""
@@ -187,7 +197,7 @@ class Path:
                 props, n_keep, self.pipe_ws = ops.rpn_proposals_nchw([cls], [reg], anchors, PRE_NMS, IMG_H, IMG_W,
                                                                      MIN_SIZE, NMS_THR, POST_NMS,
                                                                      max_slices=PIPE_ONE_CALL_SLICES,
-                                                                     rounds=self.nms_rounds, workspace=self.pipe_ws)
+                                                                     rounds=self._pipe_rounds(), workspace=self.pipe_ws)
                 mark("gather", pipe.s_prop)
                 return props, n_keep
             scores, deltas = ops.rpn_flatten([cls], [reg])
