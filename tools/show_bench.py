@@ -5,7 +5,8 @@ print("value %.0f images/s  ms/step %.4f  roofline.frac %.3f" % (d["value"], d["
 print("stage_ms", {k: round(v, 4) for k, v in d["stage_ms"].items()})
 for k in ("secondary_workload", "two_batches_in_flight", "configs3_rank_share_batch32"):
     if k in d:
-        print(k, "%.0f images/s" % d[k]["value"], {a: round(b, 4) for a, b in d[k]["stage_ms"].items()})
+        print(k, "%.0f images/s" % d[k]["value"], "(median step, GPU clock: %.0f)" % d[k].get("value_median_gpu_clock", 0) if d[k].get("value_median_gpu_clock") else "",
+              {a: round(b, 4) for a, b in d[k]["stage_ms"].items()})
 for k in ("config5_A200907_k30000_C256", "config5_A805707_k30000_C256", "config5_A200907_k30000_C256_batch64"):
     if k in d:
         c = d[k]
