@@ -335,6 +335,10 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
         step(anchors, cls, reg, feat, ev)
         extra.append(ev)
     barrier()
+    if os.environ.get("BENCH_DEBUG"):
+        for ev in extra:
+            print("BENCH_DEBUG instrumented step:", [(n1, round(e0.elapsed_time(e1), 4)) for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:])],
+                  file=sys.stderr, flush=True)
     stage_ms = stage_means(extra, np.median)  # (median of the instrumented steps: one late launch does not colour a stage)
     stage_ms["roi_align"] = roi_ms
     queue_wait = stage_ms.pop("roi_queue_wait", None)  # time RoIAlign of step i waited behind that of step i-1
