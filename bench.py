@@ -329,6 +329,10 @@ def run_workload(path, dev, dist, rank, world, B, workload, steps, warmup, pipel
     ends = [e for ev in events for (name, e) in ev if name == "roi_align"]
     steady_ms = float(np.median([a.elapsed_time(b) for a, b in zip(ends[:-1], ends[1:])])) if len(ends) > 1 else None
     # every stage: a few fully instrumented steps after the timed region
+    # (first a few of them unrecorded: the staged calls' first allocations leave the GPU waiting for the host, and its
+    # clocks take some 20 ms to come back after an idle stretch -- RoIAlign 0.83-0.89 ms in the steps right behind one)
+    for _ in range(SETTLE_STEPS):
+        step(anchors, cls, reg, feat, [])
     extra = []
     for _ in range(max(3, steps // 5)):
         ev = []
