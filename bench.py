@@ -853,17 +853,21 @@ def config5_microbench(dev, B=16, reps=5, levels=4):
         mark("roi_align")
         return nk, total
 
-    for _ in range(2):
+    # settling steps, then the recorded ones back to back (no synchronisation in between: after an idle stretch the
+    # clocks need ~20 ms to come back, see run_workload); a stage = the median over the recorded steps
+    for _ in range(max(4, 24 // max(1, B // 16))):
         step([])
-    torch.cuda.synchronize()
-    acc = {}
+    evs = []
     for _ in range(reps):
         ev = []
         nk, total = step(ev)
-        torch.cuda.synchronize()
+        evs.append(ev)
+    torch.cuda.synchronize()
+    acc = {}
+    for ev in evs:
         for (_, e0), (b, e1) in zip(ev[:-1], ev[1:]):
             acc.setdefault(b, []).append(e0.elapsed_time(e1))
-    stage = {k: float(np.mean(v)) for k, v in acc.items()}
+    stage = {k: float(np.median(v)) for k, v in acc.items()}
     ms = sum(stage.values())
     out_bytes = int(total) * x["C"] * 49 * 4
     return {"config5_A%d_k30000_C256" % x["A"]: {
