@@ -597,6 +597,27 @@ def main():
         dist.destroy_process_group()
 
 
+def settled_time(fn, reps, settle_ms=25.0):
+    """Mean HIP-event time of `reps` back-to-back calls of fn, behind enough unrecorded calls to keep the GPU busy for
+    ~settle_ms: after an idle stretch (input generation on the host) its clocks need some 20 ms to come back."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    one = max(e0.elapsed_time(e1), 1e-3)
+    for _ in range(min(2000, int(settle_ms / one) + 1)):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def hbm_probe(dev):
     """Achievable HBM rates on this device with plain streaming kernels (SURVEY 8d asks for them next to the
     8 TB/s spec): a 2 GB write-only fill and a 1 GB -> 1 GB copy."""
@@ -605,14 +626,7 @@ def hbm_probe(dev):
     b = torch.empty(n // 2, dtype=torch.float32, device=dev)
 
     def timed(fn, reps=5):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        return settled_time(fn, reps)
 
     fill = n * 4 / timed(lambda: a.fill_(1.0)) / 1e6
     copy = n * 4 / timed(lambda: b.copy_(a[:n // 2])) / 1e6   # bytes read + written
@@ -628,15 +642,7 @@ def next_rows_microbench(dev):
     B = 16
 
     def timed(fn, reps=20):
-        for _ in range(3):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        return settled_time(fn, reps)
 
     res = {}
     # row 3: batch assembly, 16 images 3x600x1000 -> max side 1000 (scale 1) -> (16,3,608,1024).  Three figures:
@@ -755,15 +761,7 @@ def targets_microbench(path, dev):
     props = torch.as_tensor(props).to(dev)
 
     def timed(fn, reps=20):
-        for _ in range(3):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        return settled_time(fn, reps)
 
     res = {}
     cases = {"anchor_target_A20646_M100": (lambda: ops.iou_label_encode(anchors, gt, None, 0.3, 0.7, None, None,
@@ -896,14 +894,7 @@ def config5_backward_microbench(dev, B=16, reps=3):
         for f in feats:
             f.grad = None
         out.backward(G, retain_graph=True)
-    run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = settled_time(run, reps)
     nbytes = int(total) * x["C"] * 49 * 4 + sum(f.numel() for f in feats) * 4
     return {"roi_align_backward_config5_B16_C256": {"ms": ms, "algorithmic_bytes": nbytes, "GBps": nbytes / ms / 1e6,
                                                     "hbm_frac": nbytes / ms / 1e6 / HBM_PEAK_GBPS}}
@@ -925,15 +916,7 @@ def roi_pool_microbench(path, dev):
                          (cy + h / 2).clip(0, IMG_H)], 1).astype(np.float32)
 
     def timed(fn, reps=5):
-        for _ in range(2):
-            fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        return settled_time(fn, reps)
 
     feat = torch.randn((B, C, FH, FW), generator=torch.Generator().manual_seed(5)).to(dev)
     props = torch.as_tensor(np.stack([boxes(K) for _ in range(B)])).to(dev)
