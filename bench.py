@@ -974,7 +974,7 @@ def nms_microbench(path, dev):
             sets["bug_compatible"] = bug_compatible(n)
         for name, (boxes, count) in sets.items():
             def timed(fn, reps=10):
-                for _ in range(3):
+                for _ in range(150):   # ~20 ms of launches: the clocks are back before anything is timed
                     keep, nk = fn()
                 torch.cuda.synchronize()   # (the bounded form learns from calls that have finished)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
