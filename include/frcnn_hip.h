@@ -245,6 +245,19 @@ int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W, c
                                 float spatial_scale, int sampling_ratio, int level, int n_levels,
                                 int k_min, int k_max, float *out, int32_t *total_out, void *stream);
 
+/* Every level of MultiScaleRoIAlign in one call (ROIHead/roi_pooling.py:44-53, call site
+ * ROIHead/roi_head.py:127-130, on the pyramid of BackBone/fpn.py:91-96): what n_levels calls of
+ * frcnn_roi_align_batched_f32 with level = 0 .. n_levels-1 produce, same row order, same zero rows for the RoIs no
+ * level takes.  feats: HOST array of n_levels device pointers (B,C,h_l,w_l); hw: HOST array (h_0,w_0,h_1,w_1,...);
+ * scales: HOST array of spatial scales; n_levels <= 6.  For 7x7 bins at sampling_ratio 2 the levels are pooled by
+ * ONE launch (tiles of each level in LDS, 16 channels per item; csrc/roi_tile.hip) plus one small launch per level
+ * of several tiles for RoIs wider than 105 cells; a single map small enough for the plane kernel, and every other
+ * bin count or sampling ratio, goes level by level through frcnn_roi_align_batched_f32. */
+int frcnn_roi_align_levels_f32(const float *const *feats, const int32_t *hw, const float *scales, int n_levels,
+                               int B, int C, const float *props, const int32_t *count, int P, int pooled_h,
+                               int pooled_w, int sampling_ratio, int k_min, int k_max, float *out,
+                               int32_t *total_out, void *stream);
+
 /* Backward of frcnn_roi_align_batched_f32 with respect to `feat`: what torch autograd runs through
  * torchvision's MultiScaleRoIAlign at ROIHead/roi_pooling.py:51-53 / ROIHead/roi_head.py:127-130 (the reference's
  * RoI losses train the backbone through the pooling).  Same arguments as the forward pass of one level;

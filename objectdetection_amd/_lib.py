@@ -52,6 +52,7 @@ SIGNATURES = {
     "frcnn_level_map_f32": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "frcnn_roi_align_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P, _P]),
     "frcnn_roi_align_batched_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "frcnn_roi_align_levels_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "frcnn_roi_align_batched_backward_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _I, _P, _P]),
     "frcnn_roi_pool_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P]),
     "frcnn_roi_pool_batched_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),

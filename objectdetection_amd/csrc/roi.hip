@@ -200,117 +200,6 @@ extern "C" int frcnn_roi_align_f32(const float *feat, int B, int C, int H, int W
 // lane = bin, so each channel store is one 196-byte run and the 16 stores of an iteration fill a
 // contiguous 3136-byte piece of the (K, C, 7, 7) output.
 
-#define RAP_THREADS 1024
-#define RAP_SEG 512 // RoIs whose geometry is staged in LDS at a time (10 KB)
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// acc += w * f for four channels as two packed fp32 FMAs (v_pk_fma_f32).
-__device__ __forceinline__ void pk_axpy4(f32x2 &lo, f32x2 &hi, float w, const float4 &f)
-{
-    f32x2 w2 = {w, w};
-    f32x2 a = {f.x, f.y}, c = {f.z, f.w};
-    lo = __builtin_elementwise_fma(w2, a, lo);
-    hi = __builtin_elementwise_fma(w2, c, hi);
-}
-
-// LDS image of a chunk: index (in float4 = 4-channel pixels) = (y * G + g) * WS + (x ^ swz(y)),
-// WS = W rounded up to 16.  The G channel groups of a row sit WS pixels apart, so with a
-// compile-time WS the per-group tap address is an IMMEDIATE ds_read offset (g * WS * 16 bytes) and
-// the 16 tap addresses of an item are computed once for all its channels.  A pixel is one 16-byte
-// slot, 16 slots span the 64 banks, and every row starts on a multiple of 16 slots, so the slot of
-// (y, x) is (x ^ swz(y)) & 15; the 4-bit bit reversal swz(y) keeps bins of neighbouring rows that
-// share a column off the same banks.
-__device__ __forceinline__ int rap_swz(int y)
-{
-    return ((y & 1) << 3) | ((y & 2) << 1) | ((y & 4) >> 1) | ((y & 8) >> 3);
-}
-
-// The two samples of a bin along one axis touch 4 cells (lo0, hi0, lo1, hi1).  When the bin is at
-// most 2 pixels wide the samples are at most one cell apart, so the 4 taps fall on 3 consecutive
-// cells a, a+1, a+2 and their weights can be added up per cell: 3 LDS reads and 3 FMAs per row
-// instead of 4 (9 instead of 16 per bin when both axes merge).  Same sum, different rounding order
-// (a few ulp; the parity tests allow 1e-5, tests/test_gpu_parity.py).
-struct AxisTaps {
-    int idx[4];
-    float w[4];
-};
-
-__device__ __forceinline__ bool axis_mergeable(const AxisSample &s0, const AxisSample &s1)
-{
-    return s0.ok && s1.ok && (unsigned)(s1.lo - s0.lo) <= 1u;
-}
-
-__device__ __forceinline__ AxisTaps axis_taps4(const AxisSample &s0, const AxisSample &s1, float k)
-{
-    AxisTaps t;
-    t.idx[0] = s0.lo; t.idx[1] = s0.hi; t.idx[2] = s1.lo; t.idx[3] = s1.hi;
-    t.w[0] = s0.wlo * k; t.w[1] = s0.whi * k; t.w[2] = s1.wlo * k; t.w[3] = s1.whi * k;
-    return t;
-}
-
-__device__ __forceinline__ AxisTaps axis_taps3(const AxisSample &s0, const AxisSample &s1, float k, int n)
-{
-    AxisTaps t;
-    const bool same = s1.lo == s0.lo;
-    const int a = s0.lo;
-    t.idx[0] = a;
-    t.idx[1] = min(a + 1, n - 1);
-    t.idx[2] = same ? a : min(a + 2, n - 1); // weight 0 when `same`: stay on a cell that is read anyway
-    t.idx[3] = 0;
-    // a clamped sample (lo == n-1) has whi == 0, so treating its hi tap as cell lo+1 is exact
-    t.w[0] = (s0.wlo + (same ? s1.wlo : 0.0f)) * k;
-    t.w[1] = (s0.whi + (same ? s1.whi : s1.wlo)) * k;
-    t.w[2] = (same ? 0.0f : s1.whi) * k;
-    t.w[3] = 0.0f;
-    return t;
-}
-
-// All channel groups of one item: NY x NX taps, each ONE ds_read_b128 serving 4 channels.
-template <int NY, int NX, int GT>
-__device__ __forceinline__ void rap_item(const float4 *s_plane, int WS, int row_stride, int G, int nc,
-                                         const AxisTaps &ty, const AxisTaps &tx, float *o)
-{
-    int off[NY * NX];
-    float wt[NY * NX];
-#pragma unroll
-    for (int r = 0; r < NY; ++r) {
-        const int rb = __mul24(ty.idx[r], row_stride);
-        const int sw = rap_swz(ty.idx[r]);
-#pragma unroll
-        for (int c = 0; c < NX; ++c) {
-            off[r * NX + c] = (tx.idx[c] ^ sw) + rb;
-            wt[r * NX + c] = ty.w[r] * tx.w[c];
-        }
-    }
-    if (GT) {
-#pragma unroll
-        for (int g = 0; g < (GT ? GT : 1); ++g) {
-            const float4 *pl = s_plane + g * WS; // immediate offset when WS is a compile-time constant
-            f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
-#pragma unroll
-            for (int q = 0; q < NY * NX; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
-            float *og = o + (4 * g) * 49; // immediate store offsets
-            og[0] = lo.x;
-            og[49] = lo.y;
-            og[98] = hi.x;
-            og[147] = hi.y;
-        }
-    } else {
-        for (int g = 0; g < G; ++g) {
-            const float4 *pl = s_plane + g * WS;
-            f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
-#pragma unroll
-            for (int q = 0; q < NY * NX; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
-            float *og = o + (4 * g) * 49;
-            og[0] = lo.x;
-            if (4 * g + 1 < nc) og[49] = lo.y;
-            if (4 * g + 2 < nc) og[98] = hi.x;
-            if (4 * g + 3 < nc) og[147] = hi.y;
-        }
-    }
-}
-
 // Staging of a chunk's planes (shared by the RoIAlign and max-RoIPool plane kernels): 4 coalesced plane reads ->
 // one 16-byte LDS write per pixel/group.  Four pixels per thread are fetched before any is written, so a
 // workgroup pays about three memory round trips for its 150 KB instead of nine.
@@ -727,6 +616,8 @@ roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, in
                 }
                 // behind the window kernel (nwy > 0): only the RoIs that fit no window are left to do
                 if (todo && !zero && nwy > 0 && roi_window(roi_record(box, scale), H, W, nwy, nwx).fits) todo = false;
+                // behind the tile kernel (nwy < 0: -nwy x -nwx tiles), which has also written the zeros
+                if (nwy < 0 && (zero || (todo && tile_roi_fits(roi_record(box, scale), H, W, -nwy, -nwx)))) todo = false;
                 if (todo) code = zero ? (j | 0x40000000) : j;
             }
             if (code >= 0) s_list[atomicAdd(&s_nl, 1)] = code;
@@ -789,7 +680,6 @@ roi_align_batched_direct_kernel(const float *__restrict__ feat, int C, int H, in
 #ifndef RAD_SPLITS_BEHIND
 #define RAD_SPLITS_BEHIND 16 // config 5: 128 -> 86 us against 128 splits (32: 88, 64: 101)
 #endif
-#define RAP_LDS_BUDGET (150 * 1024) // dynamic part (8 channels of a 50 x 96 plane); 8.7 KB of static LDS on top
 
 extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int H, int W,
                                            const float *props, const int32_t *count, int P,
@@ -914,6 +804,20 @@ extern "C" int frcnn_roi_align_batched_f32(const float *feat, int B, int C, int 
                        pooled_w, spatial_scale, sampling_ratio, level, n_levels, k_min, k_max, nwy, nwx, out,
                        total_out);
     FRCNN_CHECK_LAUNCH("roi_align_batched_direct");
+    return FRCNN_OK;
+}
+
+int frcnn_roi_align_direct_behind_tiles(const float *feat, int B, int C, int H, int W, const float *props,
+                                        const int32_t *count, int P, float spatial_scale, int level, int n_levels,
+                                        int k_min, int k_max, float *out, void *stream)
+{
+    const int chunks = (C + RA_CHUNK - 1) / RA_CHUNK;
+    FRCNN_REQUIRE(chunks <= 65535, "roi_align_levels: too many channels");
+    const int splits = P < RAD_SPLITS_BEHIND ? P : RAD_SPLITS_BEHIND;
+    hipLaunchKernelGGL(roi_align_batched_direct_kernel, dim3(splits, chunks, B), dim3(256), 0, (hipStream_t)stream, feat,
+                       C, H, W, (const float4 *)props, count, P, 7, 7, spatial_scale, 2, level, n_levels, k_min, k_max,
+                       -tile_count(H), -tile_count(W), out, (int32_t *)nullptr);
+    FRCNN_CHECK_LAUNCH("roi_align_batched_direct (behind tiles)");
     return FRCNN_OK;
 }
 

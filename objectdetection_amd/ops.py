@@ -762,17 +762,19 @@ def _roi_align_levels(cfg, props, count, feats):
     dev = props.device
     out = torch.empty((B * P, C) + tuple(output_size), dtype=torch.float32, device=dev)
     total = torch.empty((1,), dtype=torch.int32, device=dev)
-    lib = _lib.load()
+    feats = [_f32c(f) for f in feats]
+    for l, f in enumerate(feats):
+        if f.shape[0] != B or f.shape[1] != C:
+            raise ValueError("feature map %d has shape %s, expected (%d,%d,h,w)" % (l, tuple(f.shape), B, C))
+    n = len(feats)
+    ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
+    hw = (ctypes.c_int32 * (2 * n))(*[int(v) for f in feats for v in f.shape[2:]])
+    sc = (ctypes.c_float * n)(*[float(s) for s in scales])
     with torch.cuda.device(dev):
-        for l, (f, s) in enumerate(zip(feats, scales)):
-            f = _f32c(f)
-            if f.shape[0] != B or f.shape[1] != C:
-                raise ValueError("feature map %d has shape %s, expected (%d,%d,h,w)" % (l, tuple(f.shape), B, C))
-            rc = lib.frcnn_roi_align_batched_f32(
-                _ptr(f), B, C, f.shape[2], f.shape[3], _ptr(props), _ptr(count), P, output_size[0],
-                output_size[1], float(s), sampling_ratio, l, len(feats), k_min, k_max,
-                _ptr(out), _ptr(total), _stream())
-            _lib.check(rc, "roi_align_batched")
+        rc = _lib.load().frcnn_roi_align_levels_f32(
+            ptrs, hw, sc, n, B, C, _ptr(props), _ptr(count), P, output_size[0], output_size[1], sampling_ratio,
+            k_min, k_max, _ptr(out), _ptr(total), _stream())
+        _lib.check(rc, "roi_align_levels")
     return out, total
 
 

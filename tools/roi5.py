@@ -19,6 +19,9 @@ tv, ti = ops.topk_desc_nchw(x["cls"], 30000)
 boxes, _, _, count = ops.decode_clip_filter_nchw(x["anchors"], x["reg"], ti, tv, x["Himg"], x["Wimg"], 1e-3)
 keep, nk = ops.nms_sorted(boxes, count, 0.7, 2000)
 props = ops.gather_boxes(boxes, keep, nk)
+if os.environ.get("ROI5_DUMP"):
+    import numpy as np
+    np.savez(os.environ["ROI5_DUMP"], props=props.cpu().numpy(), nk=nk.cpu().numpy())
 pool = ROIPooling(['1', '2', '3', '4'], [7, 7], 2)
 fd = {str(i + 1): f for i, f in enumerate(x["feats"][::-1])}
 fn = lambda: pool.forward_padded(fd, props, nk, [(x["Himg"], x["Wimg"])])
