@@ -24,8 +24,11 @@ reference's own functions produced for them:
   negatives-first concat, gathers, losses) replayed line by line with the
   reference's utils functions                                          -> train_sampling.npz
   RPN/rpn.py:55-83 call sequence replayed with the reference's utils
-  functions and torch.topk (rpn.py itself cannot be imported: it needs
-  torchvision, which is absent)                                        -> rpn_stages.npz
+  functions and torch.topk                                             -> rpn_stages.npz
+  RPN/rpn.py, ROIHead/roi_head.py, ROIHead/roi_pooling.py THEMSELVES, imported
+  and run (RPN.forward eval + training, ROIHead.forward eval, ROIPooling.forward)
+  with `torchvision.ops` pre-seeded by a module whose nms / MultiScaleRoIAlign are
+  the CPU oracle's: the files' own orchestration, not a transcription  -> ref_modules.npz
 
 `utils.py` imports cv2 at module level (utils.py:5) only for draw_anchor_box; an empty
 module object is registered under that name so the import succeeds.  Nothing on the hot
@@ -511,6 +514,152 @@ def gen_train_sampling():
     save("train_sampling.npz", **out)
 
 
+def _seed_torchvision_with_the_oracle():
+    """torchvision is not installed here and the reference does not vendor it.  rpn.py:18,
+    roi_head.py:26 and roi_pooling.py:18 import two names from torchvision.ops; a module object that provides
+    them -- implemented by the CPU oracle's restatement of the published algorithms -- lets the reference's
+    files be imported and RUN, so that their orchestration (concat order, views, filter order, slicing) is
+    recorded from the files themselves.  The arithmetic of nms / roi_align stays what the oracle restates:
+    this route does not pin it (closed_form.npz is the independent check for those)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import oracle as orc
+
+    def nms(boxes, scores, iou_threshold):
+        keep = orc.nms(boxes.detach().numpy().astype(np.float32), scores.detach().numpy().astype(np.float32),
+                       float(iou_threshold))
+        return torch.as_tensor(np.asarray(keep, np.int64))
+
+    class MultiScaleRoIAlign(torch.nn.Module):
+        def __init__(self, featmap_names, output_size, sampling_ratio):
+            super().__init__()
+            self.featmap_names, self.output_size, self.sampling_ratio = featmap_names, output_size, sampling_ratio
+
+        def forward(self, x, boxes, image_shapes):
+            feats = [v.detach().numpy() for k, v in x.items() if k in self.featmap_names]
+            out, _ = orc.multiscale_roi_align(feats, [b.detach().numpy() for b in boxes], image_shapes,
+                                              tuple(self.output_size), self.sampling_ratio)
+            return torch.as_tensor(out)
+
+    tv, ops = types.ModuleType("torchvision"), types.ModuleType("torchvision.ops")
+    ops.nms, ops.MultiScaleRoIAlign = nms, MultiScaleRoIAlign
+    tv.ops = ops
+    sys.modules["torchvision"], sys.modules["torchvision.ops"] = tv, ops
+    return orc
+
+
+class _FixedHead(torch.nn.Module):
+    """Stands in for the (out of scope) conv head handed to the reference's RPN: returns recorded outputs."""
+
+    def __init__(self, cls, regs):
+        super().__init__()
+        self.c, self.r = cls, regs
+
+    def forward(self, feats):
+        return list(self.c), list(self.r)
+
+
+def gen_reference_modules():
+    """fixtures that the reference's own rpn.py / roi_head.py / roi_pooling.py produced by running."""
+    orc = _seed_torchvision_with_the_oracle()
+    sys.path.insert(0, os.path.join(REF, "ROIHead"))
+    import rpn as ref_rpn                      # /root/reference/code/FasterRCNN/RPN/rpn.py
+    import roi_head as ref_roi_head            # /root/reference/code/FasterRCNN/ROIHead/roi_head.py
+    import roi_pooling as ref_roi_pooling      # /root/reference/code/FasterRCNN/ROIHead/roi_pooling.py
+    for m, f in ((ref_rpn, "RPN/rpn.py"), (ref_roi_head, "ROIHead/roi_head.py"), (ref_roi_pooling, "ROIHead/roi_pooling.py")):
+        assert os.path.abspath(m.__file__) == os.path.join(REF, f), m.__file__
+    out = {}
+    # ---- RPN.forward, training mode, on the inputs of train_sampling.npz (rpn.py:46-142 in one go: proposals of
+    # the eval half AND the losses of the training half under the same seed).  The transcription in
+    # gen_train_sampling must give the very same losses: that checks the transcription against the file.
+    ts = np.load(os.path.join(HERE, "train_sampling.npz"))
+    info = tuple(int(v) for v in ts["rpn.info"])
+    fsz = [tuple(int(v) for v in hw) for hw in ts["rpn.fsz"]]
+    S, f, neg, pos = ts["rpn.params"]
+    head = _FixedHead([torch.as_tensor(ts[f"rpn.cls{l}"]) for l in range(len(fsz))],
+                      [torch.as_tensor(ts[f"rpn.reg{l}"]) for l in range(len(fsz))])
+    params = dict(anchor_generator=AnchorGenerator(), rpn_head=head, num_pre_nms=500, num_post_nms=100,
+                  nms_threshold=0.7, proposal_min_size=1e-3, pos_threshold=float(pos), neg_threshold=float(neg),
+                  num_sample=int(S), pos_fraction=float(f))
+    targets = [{"box": ts[f"rpn.b{b}.gt"].tolist()} for b in range(info[0])]
+    feats = [torch.zeros(info[0], 1, h, w) for h, w in fsz]
+    rpn = ref_rpn.RPN(params).train()
+    torch.manual_seed(int(ts["rpn.seed"]))
+    props, loss = rpn(info, feats, targets)
+    assert abs(float(loss["cls_loss"]) - float(ts["rpn.cls_loss"])) < 1e-6, "transcription and rpn.py disagree"
+    assert abs(float(loss["reg_loss"]) - float(ts["rpn.reg_loss"])) < 1e-6, "transcription and rpn.py disagree"
+    out.update({"rpn_train.pre_post": np.asarray([500, 100]), "rpn_train.cls_loss": loss["cls_loss"].detach().numpy(),
+                "rpn_train.reg_loss": loss["reg_loss"].detach().numpy()})
+    for b, p_ in enumerate(props):
+        out[f"rpn_train.props{b}"] = p_.detach().numpy()
+    # ---- RPN.forward, eval mode, on the tie-free inputs of rpn_stages.npz (rpn.py:46-85)
+    rs = np.load(os.path.join(HERE, "rpn_stages.npz"))
+    info = tuple(int(v) for v in rs["info"])
+    fsz = [tuple(int(v) for v in hw) for hw in rs["fsz"]]
+    head = _FixedHead([torch.as_tensor(rs[f"cls{l}"]) for l in range(len(fsz))],
+                      [torch.as_tensor(rs[f"reg{l}"]) for l in range(len(fsz))])
+    params = dict(params, rpn_head=head, num_pre_nms=int(rs["num_pre_nms"]), num_post_nms=60,
+                  proposal_min_size=float(rs["min_size"]))
+    rpn = ref_rpn.RPN(params).eval()
+    props, loss = rpn(info, [torch.zeros(info[0], 1, h, w) for h, w in fsz], None)
+    assert loss is None
+    out["rpn_eval.post_thr"] = np.asarray([60, 0.7])
+    for b, p_ in enumerate(props):
+        # the file's result = the transcription's filtered boxes at the oracle's keeps
+        keep = orc.nms(rs[f"b{b}.filtered"], rs[f"b{b}.filtered_score"], 0.7)[:60]
+        assert np.array_equal(p_.numpy(), rs[f"b{b}.filtered"][keep]), "rpn_stages transcription and rpn.py disagree"
+        out[f"rpn_eval.props{b}"] = p_.numpy()
+    # ---- ROIHead.forward (eval: the file forces it, roi_head.py:90) with recorded predictor outputs: lines 127-135,
+    # 167-229 of the file itself, incl. ROIPooling -> MultiScaleRoIAlign on a two-level pyramid
+    g = torch.Generator().manual_seed(60221023)
+    K, Cf = 7, 3
+    info = (3, 256, 320)
+    sizes = [(250, 300), (256, 320), (200, 310)]
+    nprops = [150, 1, 333]
+    feats = [torch.rand(3, Cf, 64, 80, generator=g), torch.rand(3, Cf, 32, 40, generator=g)]
+    props = []
+    for n in nprops:
+        cx, cy = torch.rand(n, generator=g) * 320, torch.rand(n, generator=g) * 256
+        w = 16 * 2 ** (torch.rand(n, generator=g) * 4)
+        h = 16 * 2 ** (torch.rand(n, generator=g) * 4)
+        props.append(torch.stack([(cx - w / 2).clamp(0, 320), (cy - h / 2).clamp(0, 256), (cx + w / 2).clamp(0, 320),
+                                  (cy + h / 2).clamp(0, 256)], 1))
+    N = sum(nprops)
+    logits = torch.randn(N, K, generator=g) * 2.5
+    regs = torch.randn(N, K * 4, generator=g) * 0.3
+    regs[5, 10] = 9.0                                          # above the dw clamp
+    regs[7, 8:12] = torch.tensor([0.0, 0.0, -40.0, -40.0])     # collapses: dropped by the small-box filter
+    seen = {}
+
+    class Flat(torch.nn.Module):
+        def forward(self, x):
+            seen["roi_features"] = x
+            return x.flatten(1)
+
+    class Fixed(torch.nn.Module):
+        def forward(self, x):
+            return logits, regs
+
+    hp = dict(pos_threshold=0.5, neg_threshold=0.5, num_sample=128, pos_fraction=0.25,
+              regression_weights=[10., 10., 5., 5.], score_thresh=0.05, proposal_min_size=1e-3, nms_threshold=0.5,
+              num_post_nms=40, roi_pooling=ref_roi_pooling.ROIPooling(['1', '2'], [7, 7], 2), mlp_head=Flat(),
+              predictor=Fixed())
+    roi_head = ref_roi_head.ROIHead(hp)
+    result, roi_loss = roi_head(props, feats, info, None, sizes)
+    assert roi_loss == {} and len(result) == 3 and sum(len(r["score"]) for r in result) > 20
+    out.update({"roi_eval.info": np.asarray(info), "roi_eval.sizes": np.asarray(sizes), "roi_eval.K": np.asarray(K),
+                "roi_eval.logits": logits.numpy(), "roi_eval.regs": regs.numpy(),
+                "roi_eval.params": np.asarray([0.05, 1e-3, 0.5, 40], np.float64),
+                "roi_eval.roi_features": seen["roi_features"].numpy()})
+    for l, f_ in enumerate(feats):
+        out[f"roi_eval.feat{l}"] = f_.numpy()
+    for i, (p_, r) in enumerate(zip(props, result)):
+        out[f"roi_eval.props{i}"] = p_.numpy()
+        out[f"roi_eval.b{i}.proposal"] = r["proposal"].numpy()
+        out[f"roi_eval.b{i}.score"] = r["score"].numpy()
+        out[f"roi_eval.b{i}.label"] = r["label"].numpy()
+    save("ref_modules.npz", **out)
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not present: goldens can only be generated in the build container")
@@ -523,3 +672,4 @@ if __name__ == "__main__":
     gen_sampling()
     gen_rpn_stages()
     gen_train_sampling()
+    gen_reference_modules()

@@ -1286,6 +1286,82 @@ def test_roi_head_eval_postprocess_vs_oracle(dev, oracle):
     assert total_det > 20
 
 
+def test_rpn_forward_reference_file_golden(dev):
+    """RPN.forward of the package against what the reference's RPN/rpn.py ITSELF returned when run
+    (tests/golden/make_golden.py gen_reference_modules; torchvision.ops pre-seeded with the oracle's nms): the
+    proposal lists in eval mode on tie-free two-level inputs, and proposals + both losses in training mode under
+    the same torch.manual_seed (rpn.py:46-142 as one call)."""
+    from objectdetection_amd.RPN import RPN, AnchorGenerator
+    g = load_golden("ref_modules.npz")
+    rs = load_golden("rpn_stages.npz")
+    info = tuple(int(v) for v in rs["info"])
+    fsz = [tuple(int(v) for v in hw) for hw in rs["fsz"]]
+    head = _FixedHead([T(rs[f"cls{l}"], dev) for l in range(len(fsz))], [T(rs[f"reg{l}"], dev) for l in range(len(fsz))])
+    base = dict(anchor_generator=AnchorGenerator(), nms_threshold=0.7, proposal_min_size=1e-3, pos_threshold=0.7,
+                neg_threshold=0.3, num_sample=256, pos_fraction=0.5)
+    rpn = RPN(dict(base, rpn_head=head, num_pre_nms=int(rs["num_pre_nms"]), num_post_nms=60)).eval()
+    props, loss = rpn(info, [torch.zeros(info[0], 1, h, w, device=dev) for h, w in fsz], None)
+    assert loss is None
+    for b in range(info[0]):
+        want = g[f"rpn_eval.props{b}"]
+        assert tuple(props[b].shape) == want.shape and len(want) > 0
+        np.testing.assert_allclose(props[b].cpu().numpy(), want, rtol=RTOL, atol=1e-4)
+    ts = load_golden("train_sampling.npz")
+    info = tuple(int(v) for v in ts["rpn.info"])
+    fsz = [tuple(int(v) for v in hw) for hw in ts["rpn.fsz"]]
+    S, f, neg, pos = ts["rpn.params"]
+    head = _RecordedHead([T(ts[f"rpn.cls{l}"], dev) for l in range(len(fsz))],
+                         [T(ts[f"rpn.reg{l}"], dev) for l in range(len(fsz))])
+    rpn = RPN(dict(base, rpn_head=head, num_pre_nms=500, num_post_nms=100, pos_threshold=float(pos),
+                   neg_threshold=float(neg), num_sample=int(S), pos_fraction=float(f))).train()
+    targets = [{"box": ts[f"rpn.b{b}.gt"].tolist()} for b in range(info[0])]
+    torch.manual_seed(int(ts["rpn.seed"]))
+    props, loss = rpn(info, [torch.zeros(info[0], 1, h, w, device=dev) for h, w in fsz], targets)
+    for b in range(info[0]):
+        want = g[f"rpn_train.props{b}"]
+        assert tuple(props[b].shape) == want.shape and len(want) > 0
+        np.testing.assert_allclose(props[b].detach().cpu().numpy(), want, rtol=RTOL, atol=1e-4)
+    np.testing.assert_allclose(float(loss["cls_loss"]), float(g["rpn_train.cls_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(float(loss["reg_loss"]), float(g["rpn_train.reg_loss"]), rtol=1e-5)
+
+
+def test_roi_head_eval_reference_file_golden(dev):
+    """Row f1 against a fixture the reference's file produced: ROIHead.forward of the package on the recorded
+    predictor outputs against the result dicts ROIHead/roi_head.py ITSELF returned when run (gen_reference_modules),
+    and the RoI features its ROIPooling (roi_pooling.py:49-54) handed to the head on the two-level pyramid."""
+    from objectdetection_amd.ROIHead import ROIHead, ROIPooling
+    g = load_golden("ref_modules.npz")
+    K = int(g["roi_eval.K"])
+    info = tuple(int(v) for v in g["roi_eval.info"])
+    sizes = [tuple(int(v) for v in s) for s in g["roi_eval.sizes"]]
+    st, ms, thr, post = g["roi_eval.params"]
+    seen = {}
+
+    class Flat(torch.nn.Module):
+        def forward(self, x):
+            seen["roi_features"] = x
+            return x.flatten(1)
+
+    class Fixed(torch.nn.Module):
+        def forward(self, x):
+            return T(g["roi_eval.logits"], dev), T(g["roi_eval.regs"], dev)
+
+    head = ROIHead(dict(pos_threshold=0.5, neg_threshold=0.5, num_sample=128, pos_fraction=0.25,
+                        regression_weights=[10., 10., 5., 5.], score_thresh=float(st), proposal_min_size=float(ms),
+                        nms_threshold=float(thr), num_post_nms=int(post), roi_pooling=ROIPooling(['1', '2'], [7, 7], 2),
+                        mlp_head=Flat(), predictor=Fixed()))
+    props = [T(g[f"roi_eval.props{i}"], dev) for i in range(len(sizes))]
+    feats = [T(g["roi_eval.feat0"], dev), T(g["roi_eval.feat1"], dev)]
+    result, loss = head(props, feats, info, None, sizes)
+    assert loss == {} and len(result) == len(sizes)
+    np.testing.assert_allclose(seen["roi_features"].cpu().numpy(), g["roi_eval.roi_features"], rtol=RTOL, atol=1e-6)
+    for i, r in enumerate(result):
+        assert r["label"].dtype == torch.int64
+        assert np.array_equal(r["label"].cpu().numpy(), g[f"roi_eval.b{i}.label"])
+        np.testing.assert_allclose(r["score"].cpu().numpy(), g[f"roi_eval.b{i}.score"], rtol=1e-6)
+        np.testing.assert_allclose(r["proposal"].cpu().numpy(), g[f"roi_eval.b{i}.proposal"], rtol=RTOL, atol=1e-4)
+
+
 @pytest.mark.parametrize("K,nprops,thresh", [(2, [3000, 1, 0, 2500], -1.0), (21, [400, 0, 37, 1], -1.0),
                                              (21, [2000, 1500], 0.3), (1024, [5, 2], -1.0), (1025, [4, 3], -1.0),
                                              (1, [2100, 5], -1.0)])

@@ -178,6 +178,69 @@ def test_rpn_stages(oracle):
         assert props[b].shape == (len(keep), 4)
 
 
+def _restate_roi_head_eval(oracle, props, logits, regs, sizes, K, score_thresh, min_size, nms_thr, post):
+    """ROIHead/roi_head.py:167-229 per image with the oracle's functions (fp32 softmax as torch computes it)."""
+    import torch
+    res, off = [], 0
+    for i, p_ in enumerate(props):
+        n = len(p_)
+        sc = torch.softmax(torch.as_tensor(logits[off:off + n]), -1).numpy().reshape(-1)
+        box = oracle.box_clip(oracle.box_regression(p_, regs[off:off + n]).reshape(-1, 4), sizes[i])
+        lab = np.tile(np.arange(K), n)
+        m = sc > np.float32(score_thresh)
+        box, sc, lab = box[m], sc[m], lab[m]
+        _, idx = oracle.remove_small_box(box, min_size)
+        box, sc, lab = box[idx], sc[idx], lab[idx]
+        m = lab > 0
+        box, sc, lab = box[m], sc[m], lab[m]
+        keep = oracle.nms(box, sc, nms_thr)[:post] if len(box) else np.zeros(0, np.int64)
+        res.append((box[keep], sc[keep], lab[keep]))
+        off += n
+    return res
+
+
+def test_reference_files_rpn_forward(oracle):
+    """The oracle against what RPN/rpn.py ITSELF returned when run (tests/golden/make_golden.py
+    gen_reference_modules: the file imported with torchvision.ops pre-seeded by the oracle's nms): eval on the
+    tie-free two-level inputs and training mode on the sampling inputs.  Pins rpn.py:46-85 as executed by the
+    file -- concat order, views, slicing -- not the NMS arithmetic (the stub's, i.e. the oracle's own)."""
+    g = load_golden("ref_modules.npz")
+    for name, src, post in (("rpn_eval", load_golden("rpn_stages.npz"), 60), ("rpn_train", load_golden("train_sampling.npz"), 100)):
+        pre = "" if name == "rpn_eval" else "rpn."
+        info = tuple(int(v) for v in src[pre + "info"])
+        fsz = [tuple(int(v) for v in r) for r in src[pre + "fsz"]]
+        list_cls = [src[f"{pre}cls{l}"] for l in range(len(fsz))]
+        list_regs = [src[f"{pre}reg{l}"] for l in range(len(fsz))]
+        params = dict(num_pre_nms=1000 if name == "rpn_eval" else 500, num_post_nms=post, nms_threshold=0.7,
+                      proposal_min_size=1e-3)
+        props = oracle.rpn_proposals(info, list_cls, list_regs, params)
+        for b in range(info[0]):
+            want = g[f"{name}.props{b}"]
+            assert props[b].shape == want.shape and len(want) > 0
+            np.testing.assert_allclose(props[b], want, rtol=RTOL, atol=1e-4)
+
+
+def test_reference_files_roi_head_eval(oracle):
+    """The oracle's restatement of roi_head.py:127-135,167-229 against the result dicts ROIHead/roi_head.py ITSELF
+    returned when run on recorded predictor outputs (row f1), and roi_pooling.py's output on the two-level pyramid."""
+    g = load_golden("ref_modules.npz")
+    K = int(g["roi_eval.K"])
+    sizes = [tuple(int(v) for v in s) for s in g["roi_eval.sizes"]]
+    props = [g[f"roi_eval.props{i}"] for i in range(len(sizes))]
+    st, ms, thr, post = g["roi_eval.params"]
+    res = _restate_roi_head_eval(oracle, props, g["roi_eval.logits"], g["roi_eval.regs"], sizes, K, st, ms, thr, int(post))
+    total = 0
+    for i, (box, sc, lab) in enumerate(res):
+        assert np.array_equal(lab, g[f"roi_eval.b{i}.label"])
+        np.testing.assert_allclose(sc, g[f"roi_eval.b{i}.score"], rtol=1e-6)
+        np.testing.assert_allclose(box, g[f"roi_eval.b{i}.proposal"], rtol=RTOL, atol=1e-4)
+        total += len(lab)
+    assert total > 20
+    info = tuple(int(v) for v in g["roi_eval.info"])
+    out, _ = oracle.multiscale_roi_align([g["roi_eval.feat0"], g["roi_eval.feat1"]], props, [(info[1], info[2])], (7, 7), 2)
+    np.testing.assert_allclose(out, g["roi_eval.roi_features"], rtol=RTOL, atol=1e-6)
+
+
 def test_training_half_sampling(oracle):
     """The oracle's labels + the product's host-side get_sampling_factor (CPU RNG, reference call order)
     reproduce the reference's sampled index lists of rpn.py:115-122 and roi_head.py:113-121."""
