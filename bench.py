@@ -779,7 +779,62 @@ def targets_microbench(path, dev):
                      "hbm_frac": B * bytes_img / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "pairs_per_s": pairs / (ms * 1e-3),
                      "fp32_valu_frac": pairs * 17 / (ms * 1e-3) / 157e12}
+    res.update(training_halves_wall(path, dev, gt, labels, props))
     return {"training_targets_config3": res}
+
+
+def training_halves_wall(path, dev, gt, labels, props):
+    """Config 3 end to end, wall clock with a synchronisation either side (median of 9 after 3 untimed calls):
+    `rpn_forward_train_ms` = RPN.forward in training mode on recorded head outputs (RPN/rpn.py:46-142: proposals,
+    anchor targets for 16 x 20,646 anchors x 100 boxes, the 256-per-image sampling on the host RNG in the
+    reference's order, both losses); `rpn_training_half_ms` = that minus the same call in eval mode;
+    `roi_head_targets_ms` = ROIHead's target half alone (ROIHead/roi_head.py:99-124: targets for 16 x 2,000 proposals,
+    128-per-image sampling, the three gathers).  What a user of BASELINE configs[2] waits for, not a kernel time."""
+    import time
+    from objectdetection_amd.RPN import RPN, AnchorGenerator
+    from objectdetection_amd.ROIHead import ROIHead
+    B = gt.shape[0]
+    cls, reg, feat = (t.to(dev) for t in make_batch(0, B))
+
+    class Head(torch.nn.Module):
+        def forward(self, feats):
+            return [cls], [reg]
+
+    targets = [{"box": gt[b].tolist(), "class": labels[b].tolist()} for b in range(B)]
+    rpn = RPN(dict(anchor_generator=AnchorGenerator(), rpn_head=Head(), num_pre_nms=PRE_NMS, num_post_nms=POST_NMS,
+                   nms_threshold=NMS_THR, proposal_min_size=MIN_SIZE, pos_threshold=0.7, neg_threshold=0.3,
+                   num_sample=256, pos_fraction=0.5))
+    head = ROIHead(dict(pos_threshold=0.5, neg_threshold=0.5, num_sample=128, pos_fraction=0.25,
+                        regression_weights=[10., 10., 5., 5.], score_thresh=0.05, proposal_min_size=1e-3,
+                        nms_threshold=0.5, num_post_nms=100, roi_pooling=None, mlp_head=None, predictor=None))
+    list_props = [props[b] for b in range(B)]
+
+    def roi_targets():
+        p, n, lab, rg = head._proposal_targets_padded(list_props, targets, dev)
+        valid = torch.arange(p.shape[1], device=dev)[None, :] < n[:, None]
+        flat, sizes = path.ops.sample_rows(torch.gt(lab, 0) & valid, torch.eq(lab, 0) & valid, 128, 0.25)
+        return lab.reshape(-1)[flat], rg.reshape(-1, 4)[flat], p.reshape(-1, 4)[flat]
+
+    def wall(fn):
+        for _ in range(3):
+            fn()
+        ts = []
+        for _ in range(9):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(np.median(ts))
+
+    info = (B, IMG_H, IMG_W)
+    torch.manual_seed(0)
+    t_train = wall(lambda: rpn.train()(info, [feat], targets))
+    with torch.no_grad():
+        t_eval = wall(lambda: rpn.eval()(info, [feat], None))
+    return {"rpn_forward_train_ms": t_train, "rpn_forward_eval_ms": t_eval, "rpn_training_half_ms": t_train - t_eval,
+            "roi_head_targets_ms": wall(roi_targets), "batch": B, "gt_per_image": int(gt.shape[1]),
+            "host_reads_per_batch_training_half": 1}
 
 
 def config5_inputs(B, dev, seed=7, levels=4):

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch.nn import Module
 
 from .. import ops
-from ..utils import get_sampling_factor, remove_small_box
+from ..utils import remove_small_box
 
 
 class ROIHead(Module):
@@ -33,13 +33,25 @@ class ROIHead(Module):
         self.nms_threshold = params['nms_threshold']
         self.num_post_nms = params['num_post_nms']
         self.force_eval = params.get('force_eval', True)
-        # what the last training forward sampled (roi_head.py:113-124): per image the random_index (negatives
-        # first) and the gathered labels / encodings / proposals -- observable for the sampling-order tests
-        self.last_sampled = None
+        self._sampled = None
+
+    @property
+    def last_sampled(self):
+        """What the last training forward sampled (roi_head.py:113-124): per image the random_index (negatives
+        first) and the gathered labels / encodings / proposals -- observable for the sampling-order tests."""
+        if self._sampled is None:
+            return None
+        flat, sizes, P, cls_label, reg_label, list_proposals = self._sampled
+        out, at = [], 0
+        for b, n in enumerate(sizes):
+            out.append({"random_index": flat[at:at + n] - b * P, "cls_label": cls_label[at:at + n],
+                        "reg_label": reg_label[at:at + n], "proposal": list_proposals[b]})
+            at += n
+        return out
 
     # -- proposal targets: roi_head.py:99-110, batched -------------------------------------------
-    def proposal_targets(self, list_rpn_proposals, list_targets, device):
-        """-> list over images of (cls_label (P_i,), reg_label (P_i,4))."""
+    def _proposal_targets_padded(self, list_rpn_proposals, list_targets, device):
+        """-> props (B,P,4) zero-padded, n (B) rows per image (device int64), cls_label (B,P), reg_label (B,P,4)."""
         B = len(list_rpn_proposals)
         P = max(p.shape[0] for p in list_rpn_proposals)
         m = [len(t['box']) for t in list_targets]
@@ -55,7 +67,13 @@ class ROIHead(Module):
         out = ops.iou_label_encode(props, gt.to(device), torch.tensor(m, dtype=torch.int32, device=device),
                                    self.neg_threshold, self.pos_threshold, lab.to(device), self.regression_weights,
                                    want=("label", "dev"))
-        return [(out["label"][i, :p.shape[0]], out["dev"][i, :p.shape[0]]) for i, p in enumerate(list_rpn_proposals)]
+        n = torch.tensor([p.shape[0] for p in list_rpn_proposals], device=device)
+        return props, n, out["label"], out["dev"]
+
+    def proposal_targets(self, list_rpn_proposals, list_targets, device):
+        """-> list over images of (cls_label (P_i,), reg_label (P_i,4))."""
+        _, _, label, dev_ = self._proposal_targets_padded(list_rpn_proposals, list_targets, device)
+        return [(label[i, :p.shape[0]], dev_[i, :p.shape[0]]) for i, p in enumerate(list_rpn_proposals)]
 
     def forward(self, list_rpn_proposals, list_features, batch_image_info, list_targets, list_image_size):
         if self.force_eval:
@@ -66,33 +84,17 @@ class ROIHead(Module):
 
         list_cls_label, list_reg_label, list_proposals = [], [], []
         if self.training:
-            targets = self.proposal_targets(list_rpn_proposals, list_targets, device)
-            # roi_head.py:113-114 for the whole batch: two nonzero calls on the padded label matrix (row-major:
-            # each image's indices are contiguous and ascending) instead of two host syncs per image
-            n_img = len(list_rpn_proposals)
-            p_max = max(p.shape[0] for p in list_rpn_proposals)
-            lab_pad = torch.full((n_img, p_max), -1.0, dtype=torch.float32, device=device)
-            for i, (cls_label, _) in enumerate(targets):
-                lab_pad[i, :cls_label.shape[0]] = cls_label
-            pos_all = torch.nonzero(torch.gt(lab_pad, 0))
-            neg_all = torch.nonzero(torch.eq(lab_pad, 0))
-            pos_cnt = torch.bincount(pos_all[:, 0], minlength=n_img).tolist()
-            neg_cnt = torch.bincount(neg_all[:, 0], minlength=n_img).tolist()
-            pos_off = neg_off = 0
-            self.last_sampled = []
-            for i, (proposal, (cls_label, reg_label)) in enumerate(zip(list_rpn_proposals, targets)):
-                pos_index = pos_all[pos_off:pos_off + pos_cnt[i], 1]
-                neg_index = neg_all[neg_off:neg_off + neg_cnt[i], 1]
-                pos_off += pos_cnt[i]
-                neg_off += neg_cnt[i]
-                pos_factor, neg_factor = get_sampling_factor(self.num_sample, self.pos_fraction,
-                                                             pos_index.size(0), neg_index.size(0))
-                random_index = torch.cat([neg_index[neg_factor.to(device)], pos_index[pos_factor.to(device)]])
-                list_cls_label.append(cls_label[random_index])
-                list_reg_label.append(reg_label[random_index])
-                list_proposals.append(proposal[random_index])
-                self.last_sampled.append({"random_index": random_index, "cls_label": list_cls_label[-1],
-                                          "reg_label": list_reg_label[-1], "proposal": list_proposals[-1]})
+            # roi_head.py:99-124 for the whole batch: one fused target launch, then ops.sample_rows (one host read,
+            # the reference's randperm order per image) and three gathers -- no per-image device work
+            props, n_rows, label, reg = self._proposal_targets_padded(list_rpn_proposals, list_targets, device)
+            valid = torch.arange(props.shape[1], device=device)[None, :] < n_rows[:, None]
+            flat_index, sizes = ops.sample_rows(torch.gt(label, 0) & valid, torch.eq(label, 0) & valid,
+                                                self.num_sample, self.pos_fraction)
+            cls_label = label.reshape(-1)[flat_index]
+            reg_label = reg.reshape(-1, 4)[flat_index]
+            list_proposals = list(torch.split(props.reshape(-1, 4)[flat_index], sizes))
+            list_cls_label, list_reg_label = [cls_label], [reg_label]
+            self._sampled = (flat_index, sizes, props.shape[1], cls_label, reg_label, list_proposals)
             list_rpn_proposals = list_proposals
 
         dict_feature = dict(zip([str(i + 1) for i in range(len(list_features))], list_features))

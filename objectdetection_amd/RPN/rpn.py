@@ -13,7 +13,6 @@ import torch
 from torch.nn import Module
 
 from .. import ops
-from ..utils import get_sampling_factor
 
 
 class RPN(Module):
@@ -34,9 +33,23 @@ class RPN(Module):
         # workgroups per image for the top-k (ops.topk_desc): 0 = the library's choice; set to 1 when the
         # proposal stages run beside RoIAlign on another stream (pipeline.ProposalRoIPipeline)
         self.topk_max_slices = 0
-        # what the last training forward sampled (rpn.py:115-127): per image the random_index (negatives first)
-        # and the gathered cls / reg labels -- observable so that the sampling order can be checked
-        self.last_sampled = None
+        self._sampled = None
+
+    @property
+    def last_sampled(self):
+        """What the last training forward sampled (rpn.py:115-127): per image the random_index (negatives first)
+        and the gathered cls / reg labels -- observable so that the sampling order can be checked.  Built on
+        demand: the forward itself keeps only the batch's flat index."""
+        if self._sampled is None:
+            return None
+        flat, sizes, labels, reg_labels = self._sampled
+        A = labels.shape[1]
+        out, at = [], 0
+        for b, n in enumerate(sizes):
+            idx = flat[at:at + n] - b * A
+            out.append({"random_index": idx, "cls_label": labels[b][idx], "reg_label": reg_labels[b][idx]})
+            at += n
+        return out
 
     # -- anchors ---------------------------------------------------------------------------------
     def _flat_anchors(self, batch_image_info, list_features):
@@ -107,29 +120,12 @@ class RPN(Module):
             regs = torch.cat([r.permute(0, 2, 3, 1).flatten(1, 2).reshape(batch_size, -1, 4) for r in list_regs],
                              dim=1)
             labels, reg_labels = self.anchor_targets(anchors, list_targets, device)
-            A = scores.shape[1]
-            # rpn.py:115-116 for the whole batch: two nonzero calls (row-major, so each image's indices are
-            # contiguous and ascending) instead of two host synchronisations per image
-            neg_all = torch.nonzero(torch.eq(labels, 0))
-            pos_all = torch.nonzero(torch.eq(labels, 1))
-            neg_cnt = torch.bincount(neg_all[:, 0], minlength=batch_size).tolist()
-            pos_cnt = torch.bincount(pos_all[:, 0], minlength=batch_size).tolist()
-            list_index, sampled = [], []
-            neg_off = pos_off = 0
-            for b in range(batch_size):
-                neg_index = neg_all[neg_off:neg_off + neg_cnt[b], 1]
-                pos_index = pos_all[pos_off:pos_off + pos_cnt[b], 1]
-                neg_off += neg_cnt[b]
-                pos_off += pos_cnt[b]
-                pos_factor, neg_factor = get_sampling_factor(self.num_sample, self.pos_fraction,
-                                                             pos_index.size(0), neg_index.size(0))
-                random_index = torch.cat([neg_index[neg_factor.to(device)], pos_index[pos_factor.to(device)]])
-                list_index.append(random_index + b * A)
-                sampled.append({"random_index": random_index, "cls_label": labels[b][random_index],
-                                "reg_label": reg_labels[b][random_index]})
-            self.last_sampled = sampled
+            # rpn.py:115-122 for the whole batch (ops.sample_rows): one host read, the reference's randperm order
+            flat_index, sizes = ops.sample_rows(torch.eq(labels, 1), torch.eq(labels, 0), self.num_sample,
+                                                self.pos_fraction)
+            self._sampled = (flat_index, sizes, labels, reg_labels)
             # rpn.py:123-137: the four gathers, BCE-with-logits and smooth-L1 (Q7) are one launch, with
             # gradients to the dense head outputs (ops.RpnSampledLoss)
-            cls_loss, reg_loss = ops.RpnSampledLoss.apply(scores, regs, labels, reg_labels, torch.cat(list_index))
+            cls_loss, reg_loss = ops.RpnSampledLoss.apply(scores, regs, labels, reg_labels, flat_index)
             rpn_loss = {"cls_loss": cls_loss, "reg_loss": reg_loss}
         return list_nms_proposals, rpn_loss

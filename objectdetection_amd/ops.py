@@ -660,6 +660,48 @@ def iou_label_encode(box1, box2, m_per_image, neg_threshold, pos_threshold, labe
 
 
 # ----------------------------------------------------------------------------- K6/K7 RoI ops
+def sample_rows(pos_mask, neg_mask, num_sample, pos_fraction):
+    """The random sampling of RPN/rpn.py:115-122 and ROIHead/roi_head.py:113-121 for a whole batch.
+
+    pos_mask / neg_mask: (B, N) bool on the device -- the rows `torch.where(label == 1)` / `(label == 0)` list
+    per image.  Returns (flat (S,) int64 = b * N + row, sizes: list of B ints): per image its sampled NEGATIVES
+    first, then its positives (rpn.py:122), images in order.  What must stay per image stays per image:
+    utils.get_sampling_factor draws `torch.randperm(pos_num)` then `torch.randperm(neg_num)` on the CPU's global
+    generator in the reference's order (RNG parity under torch.manual_seed).  Everything else is batched: ONE
+    host read (the B x 2 counts), ONE host-to-device copy (ranks + order), and the k-th listed row of an image is
+    found by a search in the running count of its mask -- no nonzero(), no per-image gathers."""
+    from .utils import get_sampling_factor
+    B, N = pos_mask.shape
+    dev = pos_mask.device
+    cum_pos = pos_mask.cumsum(1, dtype=torch.int32)
+    cum_neg = neg_mask.cumsum(1, dtype=torch.int32)
+    counts = torch.stack([cum_pos[:, -1], cum_neg[:, -1]], 1).tolist() if N else [[0, 0]] * B   # the one host read
+    factors = [get_sampling_factor(num_sample, pos_fraction, n_pos, n_neg) for n_pos, n_neg in counts]
+    s_pos = max([f[0].numel() for f in factors] + [1])
+    s_neg = max([f[1].numel() for f in factors] + [1])
+    sizes = [f[0].numel() + f[1].numel() for f in factors]
+    # one host buffer: (B, s_neg) ranks of the negatives, (B, s_pos) ranks of the positives (1-based: the value
+    # the running count reaches AT the wanted row), then for every sampled row its place in those two matrices
+    host = torch.ones(B * (s_neg + s_pos) + sum(sizes), dtype=torch.int32)
+    ranks = host[:B * (s_neg + s_pos)].view(B, s_neg + s_pos)
+    order = host[B * (s_neg + s_pos):]
+    at = 0
+    for b, (pos_f, neg_f) in enumerate(factors):
+        n_n, n_p = neg_f.numel(), pos_f.numel()
+        ranks[b, :n_n] = neg_f + 1
+        ranks[b, s_neg:s_neg + n_p] = pos_f + 1
+        order[at:at + n_n] = torch.arange(b * (s_neg + s_pos), b * (s_neg + s_pos) + n_n)
+        order[at + n_n:at + n_n + n_p] = torch.arange(b * (s_neg + s_pos) + s_neg, b * (s_neg + s_pos) + s_neg + n_p)
+        at += n_n + n_p
+    host = host.to(dev, non_blocking=True)
+    ranks = host[:B * (s_neg + s_pos)].view(B, s_neg + s_pos)
+    order = host[B * (s_neg + s_pos):].long()
+    rows = torch.cat([torch.searchsorted(cum_neg, ranks[:, :s_neg].contiguous()),
+                      torch.searchsorted(cum_pos, ranks[:, s_neg:].contiguous())], 1)
+    rows = rows.clamp_(max=max(N - 1, 0)) + torch.arange(B, device=dev)[:, None] * N
+    return rows.reshape(-1)[order], sizes
+
+
 def build_rois(props, count=None):
     """(B,P,4) padded proposals + per-image counts -> rois (B*P,5) compacted, total (1) int32 device."""
     _need_gpu(props, count)
