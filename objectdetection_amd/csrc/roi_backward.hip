@@ -97,6 +97,17 @@ __device__ __forceinline__ void rab_wait(RabG &g)
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(g.lo), "+v"(g.hi) : "n"(2 * (RAB_DEPTH - 1)));
 }
 
+// Leaving the walk: the compiler knows nothing of the loads issued by hand, so the registers of G[] must stay
+// allocated until every one of them (the dummy re-loads behind the last RoI included) has landed -- a load landing
+// later would overwrite whatever the allocator had put there meanwhile.  All of G[] is an operand of the drain.
+__device__ __forceinline__ void rab_drain(RabG (&G)[RAB_DEPTH])
+{
+    static_assert(RAB_DEPTH == 6, "operand list of the drain");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(G[0].lo), "+v"(G[0].hi), "+v"(G[1].lo), "+v"(G[1].hi), "+v"(G[2].lo), "+v"(G[2].hi),
+                   "+v"(G[3].lo), "+v"(G[3].hi), "+v"(G[4].lo), "+v"(G[4].hi), "+v"(G[5].lo), "+v"(G[5].hi));
+}
+
 // One RoI, two channels, lane = (q = lane / 16, li = lane % 16).  Per block of 16 columns: B = Wx (lane (q, li) reads
 // Wx[q][xb + li] and Wx[q + 4][xb + li] from the column table; entry 7 is zero), two MFMAs leave
 // T[ph][x] = sum_pw G[ph][pw] Wx[pw][x] as D rows, i.e. lane (q, li) holds T[q][x], T[q + 4][x] of channel 0 and of
@@ -236,6 +247,7 @@ __device__ __forceinline__ void rab_walk64(bool live, const float4 rec, int jidx
                         rab_load(G[d], gb, __builtin_amdgcn_readlane(jidx, E[d] >= 0 ? E[d] : e_first), C, GL);
                     }
                 }
+                rab_drain(G);
             }
         }
         base = __builtin_amdgcn_readlane(pre, done + m - 1);

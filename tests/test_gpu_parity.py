@@ -581,6 +581,75 @@ def test_roi_pooling_single_level_vs_oracle(dev, oracle, C, H, W, Himg, Wimg, co
     assert torch.equal(got, got2)
 
 
+def _bins_with_a_sample_outside(props, scale, H, W):
+    """(n, 49) bool: bins one of whose 2 x 2 samples lies outside [-1, H] x [-1, W] (fp32, the kernels' expression)."""
+    f = np.float32
+    p = np.asarray(props, np.float32)
+    sw, sh = p[:, 0] * f(scale), p[:, 1] * f(scale)
+    bw = np.maximum(p[:, 2] * f(scale) - sw, f(1)) / f(7)
+    bh = np.maximum(p[:, 3] * f(scale) - sh, f(1)) / f(7)
+    out_y = np.zeros((len(p), 7), bool)
+    out_x = np.zeros((len(p), 7), bool)
+    for q in range(7):
+        for i in range(2):
+            y = sh + f(q) * bh + (f(i) + f(0.5)) * bh / f(2)
+            x = sw + f(q) * bw + (f(i) + f(0.5)) * bw / f(2)
+            out_y[:, q] |= (y < -1) | (y > H)
+            out_x[:, q] |= (x < -1) | (x > W)
+    return (out_y[:, :, None] | out_x[:, None, :]).reshape(len(p), 49)
+
+
+@pytest.mark.parametrize("fsz", [[(37, 62)], [(100, 168), (50, 84), (25, 42)]])
+def test_roi_align_non_finite_features_stay_where_documented(dev, oracle, fsz):
+    """DESIGN.md section 8.6, pinned so that it cannot widen silently.  A sample outside [-1, H] x [-1, W] carries
+    weight 0; torchvision's device kernel returns before reading anything for it (the oracle's rule,
+    oracle/frcnn_oracle.c), its CPU kernel multiplies feature[0] by that 0, and the kernels here multiply SOME cell of the
+    map by it.  So with Inf / NaN in a map: (1) every bin without such a sample agrees with the oracle, finite or
+    not; (2) a bin WITH one may come out non-finite where the oracle's is finite -- and nothing else may;
+    (3) finite maps are not affected.  RoIs clipped to the image (everything the RPN emits) have no such sample."""
+    from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+    rng = np.random.default_rng(77)
+    B, C = 2, 4
+    Himg, Wimg = (600, 1000) if len(fsz) == 1 else (800, 1344)
+    feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for h, w in fsz]
+    for f_ in feats:
+        f_[:, 1, 0, 0] = np.inf                  # channel 1: Inf in the corner cell (where weightless taps tend to land)
+        f_[:, 2, -1, -1] = np.nan                # channel 2: NaN in the opposite corner
+        f_[:, 2, f_.shape[2] // 2, f_.shape[3] // 2] = -np.inf
+    n = 120
+    props = [realistic_boxes(rng, n, Wimg, Himg) for _ in range(B)]
+    for p_ in props:                             # a third of the boxes stick out of the image on some side
+        k = n // 3
+        p_[:k, 0] -= rng.uniform(20, 200, k)
+        p_[:k, 2] += rng.uniform(20, 400, k)
+        p_[k // 2:k, 1] -= rng.uniform(20, 200, k - k // 2)
+        p_[k // 2:k, 3] += rng.uniform(20, 300, k - k // 2)
+    ref, lvl = oracle.multiscale_roi_align(feats, props, [(Himg, Wimg)], (7, 7), 2)
+    pool = ROIPooling([str(i + 1) for i in range(len(fsz))], [7, 7], 2)
+    got = pool({str(i + 1): T(f_, dev) for i, f_ in enumerate(feats)}, [T(p_, dev) for p_ in props],
+               [(Himg, Wimg)]).cpu().numpy()
+    allp = np.concatenate(props)
+    lvl = np.zeros(len(allp), int) if len(fsz) == 1 else np.asarray(lvl)
+    outside = np.zeros((len(allp), 49), bool)
+    for l, (h, w) in enumerate(fsz):
+        sel = lvl == l
+        outside[sel] = _bins_with_a_sample_outside(allp[sel], 2.0 ** round(float(np.log2(h / Himg))), h, w)
+    assert outside.any() and (~outside).any()
+    got, ref = got.reshape(len(allp), C, 49), ref.reshape(len(allp), C, 49)
+    inside = np.broadcast_to(~outside[:, None, :], got.shape)
+    # (1) bins whose samples are all inside: the oracle's value, finite or not
+    assert np.array_equal(np.isfinite(got[inside]), np.isfinite(ref[inside]))
+    both = inside & np.isfinite(ref)
+    np.testing.assert_allclose(got[both], ref[both], rtol=RTOL, atol=1e-5)
+    assert (inside & ~np.isfinite(ref)).any()     # (Inf or NaN may differ: a merged tap adds 0 x Inf to an Inf)
+    # (2) bins with a sample outside: finite ones agree; non-finite ones are the documented divergence
+    edge = ~inside & np.isfinite(got) & np.isfinite(ref)
+    np.testing.assert_allclose(got[edge], ref[edge], rtol=RTOL, atol=1e-5)
+    assert not (np.isfinite(got) & ~np.isfinite(ref)).any()          # never finite where the oracle is not
+    # (3) the finite channels are untouched
+    np.testing.assert_allclose(got[:, [0, 3]], ref[:, [0, 3]], rtol=RTOL, atol=1e-5)
+
+
 def test_multiscale_roi_align_vs_oracle(dev, oracle):
     """FPN pyramid, fine-to-coarse order: level assignment bit-exact, values 1e-5."""
     from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
