@@ -258,6 +258,24 @@ int frcnn_roi_align_levels_f32(const float *const *feats, const int32_t *hw, con
                                int pooled_w, int sampling_ratio, int k_min, int k_max, float *out,
                                int32_t *total_out, void *stream);
 
+/* The same pooling with LANES = CHANNELS on channel-innermost maps (csrc/roi_cl.hip; same reference lines:
+ * ROIHead/roi_pooling.py:44-53, ROIHead/roi_head.py:127-130, BackBone/fpn.py:91-96).  A wave takes (RoI, 64
+ * channels), loads coalesced 256-byte pieces of cells straight from L2, keeps the 49 sums of a channel in registers
+ * and contracts every cell row of a RoI's footprint once; no LDS staging, no RoI size limit.
+ * maps_channels_last != 0: feats[l] is laid out (B, h_l, w_l, C) (torch.channels_last memory) and read in place;
+ * maps_channels_last == 0: feats[l] is (B, C, h_l, w_l) and is first copied to that layout inside `workspace`.
+ * Same outputs as frcnn_roi_align_levels_f32 (row order, zero rows, total_out), values equal up to the summation
+ * order.  Needs 7 x 7 bins, sampling_ratio 2, C % 64 == 0, P < 2^24, h_l * w_l * C * 4 < 2^31 (FRCNN_EINVAL
+ * otherwise); workspace: frcnn_roi_align_levels_cl_workspace_bytes(...) bytes (0 = unsupported shape), 256-byte
+ * aligned, caller-owned, contents need not survive between calls. */
+size_t frcnn_roi_align_levels_cl_workspace_bytes(const int32_t *hw, int n_levels, int B, int C, int P,
+                                                 int maps_channels_last);
+int frcnn_roi_align_levels_cl_f32(const float *const *feats, const int32_t *hw, const float *scales, int n_levels,
+                                  int B, int C, int maps_channels_last, const float *props, const int32_t *count,
+                                  int P, int pooled_h, int pooled_w, int sampling_ratio, int k_min, int k_max,
+                                  float *out, int32_t *total_out, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+
 /* Backward of frcnn_roi_align_batched_f32 with respect to `feat`: what torch autograd runs through
  * torchvision's MultiScaleRoIAlign at ROIHead/roi_pooling.py:51-53 / ROIHead/roi_head.py:127-130 (the reference's
  * RoI losses train the backbone through the pooling).  Same arguments as the forward pass of one level;

@@ -53,6 +53,9 @@ SIGNATURES = {
     "frcnn_roi_align_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _I, _P, _I, _P, _P]),
     "frcnn_roi_align_batched_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _I, _P, _P, _P]),
     "frcnn_roi_align_levels_f32": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "frcnn_roi_align_levels_cl_workspace_bytes": (_Z, [_P, _I, _I, _I, _I, _I]),
+    "frcnn_roi_align_levels_cl_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _Z,
+                                           _P]),
     "frcnn_roi_align_batched_backward_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _I, _P, _P]),
     "frcnn_roi_pool_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P]),
     "frcnn_roi_pool_batched_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),

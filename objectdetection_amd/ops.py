@@ -11,6 +11,7 @@ imports those two names (RPN/rpn.py:18, ROIHead/roi_head.py:26, ROIHead/roi_pool
 """
 import collections
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -796,7 +797,29 @@ def infer_scale(feature_hw, image_hw):
     return scales[0]
 
 
-def _roi_align_levels(cfg, props, count, feats):
+# Which kernels pool a pyramid: "cl" = lanes-are-channels on channel-innermost maps (csrc/roi_cl.hip), "tiles" = LDS
+# tiles of NCHW maps (csrc/roi_tile.hip).  "auto" takes cl for maps that already are channels-last (read in place:
+# 0.84 ms against 0.82 + a 0.15 ms copy at BASELINE configs[4]) and tiles for NCHW maps (cl would first copy them:
+# 0.99 ms); DESIGN.md section 4 has the measurements.
+ROI_LEVELS_PATH = os.environ.get("FRCNN_ROI_LEVELS_PATH", "auto")
+_cl_workspaces = {}
+
+
+def _cl_workspace(dev, nbytes):
+    """One workspace per (device, stream): calls on a stream are ordered, so the next call may overwrite it."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _cl_workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=dev)
+        _cl_workspaces[key] = ws
+    return ws
+
+
+def _is_channels_last(f):
+    return f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) and not f.is_contiguous()
+
+
+def _roi_align_levels(cfg, props, count, feats, path=None):
     """Forward of every level: (out (B*P, C, oh, ow), total (1) int32)."""
     output_size, sampling_ratio, scales, k_min, k_max = cfg
     B, P = props.shape[0], props.shape[1]
@@ -804,16 +827,34 @@ def _roi_align_levels(cfg, props, count, feats):
     dev = props.device
     out = torch.empty((B * P, C) + tuple(output_size), dtype=torch.float32, device=dev)
     total = torch.empty((1,), dtype=torch.int32, device=dev)
-    feats = [_f32c(f) for f in feats]
     for l, f in enumerate(feats):
         if f.shape[0] != B or f.shape[1] != C:
             raise ValueError("feature map %d has shape %s, expected (%d,%d,h,w)" % (l, tuple(f.shape), B, C))
     n = len(feats)
-    ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
     hw = (ctypes.c_int32 * (2 * n))(*[int(v) for f in feats for v in f.shape[2:]])
     sc = (ctypes.c_float * n)(*[float(s) for s in scales])
+    lib = _lib.load()
+    path = path or ROI_LEVELS_PATH
+    cl_maps = all(f.dtype == torch.float32 and _is_channels_last(f) for f in feats)
+    if path == "auto":
+        fits_plane = n == 1 and feats[0].shape[2] * ((feats[0].shape[3] + 15) // 16 * 16) * 64 <= 150 * 1024
+        path = "cl" if cl_maps and not fits_plane else "tiles"
+    if path == "cl" and tuple(output_size) == (7, 7) and sampling_ratio == 2 and P > 0:
+        nbytes = lib.frcnn_roi_align_levels_cl_workspace_bytes(hw, n, B, C, P, int(cl_maps))
+        if nbytes > 0:
+            feats = [f if cl_maps else _f32c(f) for f in feats]
+            ws = _cl_workspace(dev, nbytes)
+            ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
+            with torch.cuda.device(dev):
+                rc = lib.frcnn_roi_align_levels_cl_f32(
+                    ptrs, hw, sc, n, B, C, int(cl_maps), _ptr(props), _ptr(count), P, 7, 7, 2, k_min, k_max,
+                    _ptr(out), _ptr(total), _ptr(ws), ws.numel(), _stream())
+                _lib.check(rc, "roi_align_levels_cl")
+            return out, total
+    feats = [_f32c(f) for f in feats]
+    ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
     with torch.cuda.device(dev):
-        rc = _lib.load().frcnn_roi_align_levels_f32(
+        rc = lib.frcnn_roi_align_levels_f32(
             ptrs, hw, sc, n, B, C, _ptr(props), _ptr(count), P, output_size[0], output_size[1], sampling_ratio,
             k_min, k_max, _ptr(out), _ptr(total), _stream())
         _lib.check(rc, "roi_align_levels")

@@ -708,6 +708,142 @@ def test_multiscale_roi_align_config5_scale(dev, oracle):
     np.testing.assert_allclose(out[:2000].cpu().numpy(), ref, rtol=RTOL, atol=1e-5)
 
 
+def _cl_case_boxes(rng, counts, Wimg, Himg):
+    props = []
+    for n in counts:
+        s = np.exp(rng.uniform(np.log(4), np.log(max(Himg, Wimg) * 1.2), (n, 2)))
+        c = rng.uniform(-0.1, 1.1, (n, 2)) * [Wimg, Himg]
+        props.append(np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32))
+    return props
+
+
+@pytest.mark.parametrize("C,fsz,stride", [
+    (64, [(37, 62)], 16), (128, [(200, 336), (100, 168), (50, 84), (25, 42)], 4), (192, [(96, 128), (48, 64), (24, 32)], 8),
+    (64, [(1, 1)], 64), (64, [(2, 70)], 16), (256, [(100, 168), (50, 84), (25, 42), (13, 21)], 8)])
+def test_roi_align_lanes_are_channels_path_vs_oracle(dev, oracle, C, fsz, stride):
+    """csrc/roi_cl.hip (lanes = channels, frcnn_roi_align_levels_cl_f32) against the oracle, on maps that are
+    channels-last (read in place) and on NCHW maps (copied into the workspace first): boxes inside, across and
+    outside the map, tiny and map-sized, a NaN-level box (zero rows), ragged counts incl. an image without boxes.
+    The two layouts run the same arithmetic: their outputs are equal bit for bit."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(C + len(fsz) + fsz[0][1])
+    B = 3
+    Himg, Wimg = fsz[0][0] * stride, fsz[0][1] * stride
+    feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for h, w in fsz]
+    counts = [70, 0, 23]
+    props = _cl_case_boxes(rng, counts, Wimg, Himg)
+    props[0][0] = [10, 10, 5, 20]                                     # negative area: NaN level, zero rows
+    props[0][1] = [0, 0, Wimg, Himg]                                  # the whole image
+    props[0][2] = [Wimg - 3, Himg - 3, Wimg, Himg]                    # the last cell
+    props[0][3] = [Wimg + 40, 10, Wimg + 90, 60]                      # beside the map
+    props[0][4] = [33.3, 47.1, 33.3, 47.1]                            # zero size
+    ref, _ = oracle.multiscale_roi_align(feats, props, [(Himg, Wimg)], (7, 7), 2)
+    P = 70
+    padded = np.zeros((B, P, 4), np.float32)
+    for b, p_ in enumerate(props):
+        padded[b, :len(p_)] = p_
+    pool = ops.MultiScaleRoIAlign([str(i + 1) for i in range(len(fsz))], (7, 7), 2)
+    levels = pool._levels({str(i + 1): T(f, dev) for i, f in enumerate(feats)}, [(Himg, Wimg)])
+    fd, scales, k_min, k_max = levels
+    cfg = ((7, 7), 2, tuple(float(s_) for s_ in scales), int(k_min), int(k_max))
+    pd, cd = T(padded, dev), T(counts, dev, torch.int32)
+    n = sum(counts)
+    outs = []
+    for cl_maps in (False, True):
+        maps = [f.contiguous(memory_format=torch.channels_last) for f in fd] if cl_maps else fd
+        out, total = ops._roi_align_levels(cfg, pd, cd, maps, path="cl")
+        assert int(total) == n
+        np.testing.assert_allclose(out[:n].cpu().numpy(), ref, rtol=RTOL, atol=2e-5,
+                                   err_msg="C=%d planes=%s channels_last=%s" % (C, fsz, cl_maps))
+        outs.append(out[:n].clone())
+    assert torch.equal(outs[0], outs[1])
+    # and the tile / plane kernels agree with it to the same tolerance (different summation order)
+    tiles, _ = ops._roi_align_levels(cfg, pd, cd, fd, path="tiles")
+    np.testing.assert_allclose(tiles[:n].cpu().numpy(), outs[0].cpu().numpy(), rtol=RTOL, atol=2e-5)
+    # channels-last maps go down this path by themselves (auto) unless the plane kernel holds the map
+    auto, _ = ops._roi_align_levels(cfg, pd, cd, [f.contiguous(memory_format=torch.channels_last) for f in fd])
+    np.testing.assert_allclose(auto[:n].cpu().numpy(), ref, rtol=RTOL, atol=2e-5)
+
+
+def test_roi_align_lanes_are_channels_rejects_what_it_cannot_do(dev):
+    """C not a multiple of 64, other bin counts: the entry point refuses (FRCNN_EINVAL) and the wrapper falls back
+    to the tile / plane kernels instead of computing something else."""
+    from objectdetection_amd import ops, _lib
+    lib = _lib.load()
+    import ctypes
+    hw = (ctypes.c_int32 * 2)(50, 84)
+    assert lib.frcnn_roi_align_levels_cl_workspace_bytes(hw, 1, 2, 48, 10, 0) == 0
+    assert lib.frcnn_roi_align_levels_cl_workspace_bytes(hw, 1, 2, 64, 10, 0) > \
+        lib.frcnn_roi_align_levels_cl_workspace_bytes(hw, 1, 2, 64, 10, 1) > 0
+    f = torch.randn(2, 48, 50, 84, device=dev)
+    props = torch.tensor([[[8.0, 8.0, 100.0, 90.0]], [[30.0, 20.0, 300.0, 200.0]]], device=dev)
+    cfg = ((7, 7), 2, (0.125,), 3, 3)
+    a, _ = ops._roi_align_levels(cfg, props, None, [f], path="cl")      # falls back: C = 48
+    b, _ = ops._roi_align_levels(cfg, props, None, [f], path="tiles")
+    assert torch.equal(a, b)
+    out = torch.empty(2, 64, 7, 7, device=dev)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    ptrs = (ctypes.c_void_p * 1)(f.data_ptr())
+    sc = (ctypes.c_float * 1)(0.125)
+    rc = lib.frcnn_roi_align_levels_cl_f32(ptrs, hw, sc, 1, 2, 48, 0, ctypes.c_void_p(props.data_ptr()), None, 1, 7, 7, 2,
+                                           3, 3, ctypes.c_void_p(out.data_ptr()), None, ctypes.c_void_p(ws.data_ptr()),
+                                           ws.numel(), None)
+    assert rc != 0 and b"multiple of 64" in lib.frcnn_last_error_string()
+    rc = lib.frcnn_roi_align_levels_cl_f32(ptrs, hw, sc, 1, 2, 64, 0, ctypes.c_void_p(props.data_ptr()), None, 1, 7, 7, 2,
+                                           3, 3, ctypes.c_void_p(out.data_ptr()), None, ctypes.c_void_p(ws.data_ptr()),
+                                           16, None)
+    assert rc != 0 and b"workspace" in lib.frcnn_last_error_string()
+
+
+def test_roi_align_lanes_are_channels_non_finite_features(dev, oracle):
+    """The rule of test_roi_align_non_finite_features_stay_where_documented for csrc/roi_cl.hip: a cell row is added
+    to a bin row only where it carries weight there, so bins whose samples all lie inside the map have the oracle's
+    finiteness exactly; only a bin with a sample outside [-1, H] x [-1, W] may turn non-finite where the oracle's
+    stays finite (a weightless x tap still multiplies some cell of the row)."""
+    from objectdetection_amd import ops
+    rng = np.random.default_rng(78)
+    B, C = 2, 64
+    fsz = [(100, 168), (50, 84), (25, 42)]
+    Himg, Wimg = 800, 1344
+    feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for h, w in fsz]
+    for f_ in feats:
+        f_[:, 1, 0, 0] = np.inf
+        f_[:, 2, -1, -1] = np.nan
+        f_[:, 2, f_.shape[2] // 2, f_.shape[3] // 2] = -np.inf
+        f_[:, 40, f_.shape[2] // 3, :] = np.inf                       # a whole row of one channel
+    n = 120
+    props = [realistic_boxes(rng, n, Wimg, Himg) for _ in range(B)]
+    for p_ in props:
+        k = n // 3
+        p_[:k, 0] -= rng.uniform(20, 200, k)
+        p_[:k, 2] += rng.uniform(20, 400, k)
+        p_[k // 2:k, 1] -= rng.uniform(20, 200, k - k // 2)
+        p_[k // 2:k, 3] += rng.uniform(20, 300, k - k // 2)
+    ref, lvl = oracle.multiscale_roi_align(feats, props, [(Himg, Wimg)], (7, 7), 2)
+    pool = ops.MultiScaleRoIAlign(['1', '2', '3'], (7, 7), 2)
+    fd, scales, k_min, k_max = pool._levels({str(i + 1): T(f, dev) for i, f in enumerate(feats)}, [(Himg, Wimg)])
+    cfg = ((7, 7), 2, tuple(float(s_) for s_ in scales), int(k_min), int(k_max))
+    got, total = ops._roi_align_levels(cfg, T(np.stack(props), dev), None, fd, path="cl")
+    got = got.cpu().numpy()
+    allp = np.concatenate(props)
+    lvl = np.asarray(lvl)
+    outside = np.zeros((len(allp), 49), bool)
+    for l, (h, w) in enumerate(fsz):
+        sel = lvl == l
+        outside[sel] = _bins_with_a_sample_outside(allp[sel], 2.0 ** round(float(np.log2(h / Himg))), h, w)
+    assert outside.any() and (~outside).any()
+    got, ref = got.reshape(len(allp), C, 49), ref.reshape(len(allp), C, 49)
+    inside = np.broadcast_to(~outside[:, None, :], got.shape)
+    assert np.array_equal(np.isfinite(got[inside]), np.isfinite(ref[inside]))
+    both = inside & np.isfinite(ref)
+    np.testing.assert_allclose(got[both], ref[both], rtol=RTOL, atol=1e-5)
+    assert (inside & ~np.isfinite(ref)).any()
+    edge = ~inside & np.isfinite(got) & np.isfinite(ref)
+    np.testing.assert_allclose(got[edge], ref[edge], rtol=RTOL, atol=1e-5)
+    assert not (np.isfinite(got) & ~np.isfinite(ref)).any()
+    np.testing.assert_allclose(got[:, [0, 3, 63]], ref[:, [0, 3, 63]], rtol=RTOL, atol=1e-5)
+
+
 @pytest.mark.parametrize("C,H,W", [(20, 100, 168), (16, 70, 49), (5, 200, 336)])
 def test_roi_align_window_kernel_edges(dev, oracle, C, H, W):
     """Planes too large for LDS (window kernel + direct kernel for the RoIs that fit no window): RoIs on

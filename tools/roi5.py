@@ -12,6 +12,7 @@ from objectdetection_amd import ops
 from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+warm = int(os.environ.get("ROI5_WARM", "3"))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dev = torch.device("cuda:0")
 x = bench.config5_inputs(B, dev)
@@ -23,9 +24,22 @@ if os.environ.get("ROI5_DUMP"):
     import numpy as np
     np.savez(os.environ["ROI5_DUMP"], props=props.cpu().numpy(), nk=nk.cpu().numpy())
 pool = ROIPooling(['1', '2', '3', '4'], [7, 7], 2)
-fd = {str(i + 1): f for i, f in enumerate(x["feats"][::-1])}
+feats = x["feats"][::-1]
+if os.environ.get("ROI5_CL_MAPS"):   # maps already channel-innermost (torch.channels_last): the cl path reads them in place
+    feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+fd = {str(i + 1): f for i, f in enumerate(feats)}
+if os.environ.get("ROI5_COMPARE"):   # the cl path against the tile path on the same inputs
+    ops.ROI_LEVELS_PATH = "tiles"
+    a, ta = pool.forward_padded(fd, props, nk, [(x["Himg"], x["Wimg"])])
+    ops.ROI_LEVELS_PATH = "cl"
+    b_, tb = pool.forward_padded(fd, props, nk, [(x["Himg"], x["Wimg"])])
+    n_ = int(ta)
+    d = (a[:n_] - b_[:n_]).abs()
+    print("compare: total %d / %d, max abs diff %.3e, max |a| %.3e, rows differing by > 1e-4: %d"
+          % (n_, int(tb), float(d.max()), float(a[:n_].abs().max()), int((d.flatten(1).max(1).values > 1e-4).sum())))
+    ops.ROI_LEVELS_PATH = os.environ.get("FRCNN_ROI_LEVELS_PATH", "auto")
 fn = lambda: pool.forward_padded(fd, props, nk, [(x["Himg"], x["Wimg"])])
-for _ in range(3):
+for _ in range(warm):
     out, total = fn()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
