@@ -944,11 +944,43 @@ def config5_microbench(dev, B=16, reps=5, levels=4):
     stage = {k: float(np.median(v)) for k, v in acc.items()}
     ms = sum(stage.values())
     out_bytes = int(total) * x["C"] * 49 * 4
-    return {"config5_A%d_k30000_C256" % x["A"]: {
+    map_bytes = sum(f.numel() for f in x["feats"]) * 4
+    res = {
         "batch": B, "ms_per_step": ms, "images_per_s": B / (ms * 1e-3), "stage_ms": stage,
         "rois_per_step": int(total), "keeps_per_img_mean": float(nk.float().mean()),
         "roi_align_write_GBps": out_bytes / (stage["roi_align"] * 1e-3) / 1e9,
-        "roi_align_hbm_frac": out_bytes / (stage["roi_align"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+        "roi_align_hbm_frac": out_bytes / (stage["roi_align"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        # reads + writes: every RoI's (C, 7, 7) block written once, every level's maps read once
+        "roi_align_roofline": {"bound": "hbm", "algorithmic_bytes": out_bytes + map_bytes,
+                               "achieved": (out_bytes + map_bytes) / (stage["roi_align"] * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": (out_bytes + map_bytes) / (stage["roi_align"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "kernel": "roi_align_tile_kernel (NCHW maps: LDS tiles, all levels in one launch)"}}
+    if levels == 4 and B <= 16:
+        # The pooling alone, by kernel family (settled, HIP events): LDS tiles of the NCHW maps (the default for NCHW),
+        # lanes = channels (csrc/roi_cl.hip) on the same NCHW maps (copied to channel-innermost first) and on maps that
+        # already are channels-last (read in place: the default for such maps).
+        boxes, keep, nk2 = _config5_keeps(ops, x, rounds)
+        props = ops.gather_boxes(boxes, keep, nk2)
+        pool2 = ops.MultiScaleRoIAlign([str(i + 1) for i in range(levels)], (7, 7), 2)
+        fl, scales, k_min, k_max = pool2._levels(fd, [(x["Himg"], x["Wimg"])])
+        cfg = ((7, 7), 2, tuple(float(s_) for s_ in scales), int(k_min), int(k_max))
+        fl_cl = [f.contiguous(memory_format=torch.channels_last) for f in fl]
+        paths = {}
+        for name, maps, pth in (("tiles_nchw_maps", fl, "tiles"), ("lanes_channels_nchw_maps", fl, "cl"),
+                                ("lanes_channels_channels_last_maps", fl_cl, "cl")):
+            t = settled_time(lambda: ops._roi_align_levels(cfg, props, nk2, maps, path=pth), reps=10)
+            paths[name] = {"ms": t, "hbm_frac_reads_and_writes": (out_bytes + map_bytes) / t / 1e6 / HBM_PEAK_GBPS}
+        res["roi_align_by_kernel_family"] = paths
+        del fl_cl
+    return {"config5_A%d_k30000_C256" % x["A"]: res}
+
+
+def _config5_keeps(ops, x, rounds):
+    tv, ti = ops.topk_desc_nchw(x["cls"], 30000)
+    boxes, _, _, count = ops.decode_clip_filter_nchw(x["anchors"], x["reg"], ti, tv, x["Himg"], x["Wimg"], 1e-3)
+    keep, nk = ops.nms_sorted(boxes, count, 0.7, 2000, rounds=rounds)
+    return boxes, keep, nk
 
 
 def config5_backward_microbench(dev, B=16, reps=3):
