@@ -416,17 +416,33 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()  # ends when rank 0 closes its stdout (exit included)
-    codes = []
-    for p in procs:
-        try:
-            codes.append(p.wait(timeout=300))
-        except subprocess.TimeoutExpired:  # rank 0 is gone and this one still runs: it is stuck in a collective
-            p.kill()
-            codes.append(p.wait())
-    sys.stdout.write(out0)
+    # rank 0's pipe is drained by a thread; every child is polled: as soon as one exits non-zero the others -- which may
+    # sit in a collective waiting for it (RCCL gives up after ten minutes, gloo possibly never) -- are killed
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "1500"))
+    failed = False
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        failed = any(c not in (None, 0) for c in codes)
+        if failed or time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            codes = [c if c is not None else "killed" for c in codes]
+            for p in procs:
+                p.wait()
+            failed = True
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    if any(codes):
+    if failed or any(codes):
         sys.exit("bench.py: ranks exited with %r" % (codes,))
 
 
@@ -438,6 +454,8 @@ def dry_run(args, world, rank):
     from objectdetection_amd.sharding import gather_proposals
     if world > 1:
         dist.init_process_group("gloo")
+    if os.environ.get("BENCH_TEST_FAIL_RANK") == str(rank):  # test hook: this rank dies before the first collective
+        sys.exit(3)
     B = args.batch
     props = torch.full((B, 8, 4), float(rank))
     n_keep = torch.full((B,), rank + 1, dtype=torch.int32)

@@ -170,7 +170,10 @@ int frcnn_nms_sorted_f32(const float *boxes, const int32_t *n_per_image, int B, 
  * not done by itself, 64 candidates at a time: slow when it has much to do, and exact -- keep lists never depend on max_blocks (max_blocks <= 0, or
  * min(max_keep, max_n) > 2048: every round, no tail).  rounds_used: (B) int32, device or host-mapped (pinned) memory,
  * or NULL; written once, by the call's last launch: per image the 64-candidate blocks that had work to do.  A caller
- * feeds max(rounds_used) + slack of one batch to the next call (objectdetection_amd.ops.NmsRounds: slack = 4). */
+ * feeds max(rounds_used) + slack of one batch to the next call (objectdetection_amd.ops.NmsRounds: slack = 4).
+ * LIFETIME: the kernels store into rounds_used when the call's last launch RUNS, not when this function returns: the
+ * memory must stay valid (and, if pinned host memory, must not be handed back to an allocator that may reuse it)
+ * until that launch has finished on `stream` -- the Python binding keeps its pinned words for the life of the process. */
 int frcnn_nms_sorted_rounds_f32(const float *boxes, const int32_t *n_per_image, int B, int max_n,
                                 double iou_threshold, int max_keep, int32_t *keep_out,
                                 int32_t *n_keep_out, void *workspace, size_t workspace_bytes,

@@ -70,10 +70,14 @@ class RPN(Module):
             # rpn.py:56-57 never materialised, and rpn.py:65-85 as ONE library call: top-k and decode read the head's
             # NCHW outputs where they lie, NMS and the gather follow on the same stream, intermediates in one
             # workspace kept across steps
-            props, n_keep, self._path_ws = ops.rpn_proposals_nchw(
+            # (one workspace per device and stream: calls on a stream are ordered behind each other, calls on two
+            # streams are not, and would overwrite each other's intermediates in a shared one)
+            cache = self.__dict__.setdefault("_path_ws", {})
+            key = (anchors.device.index, torch.cuda.current_stream(anchors.device).cuda_stream)
+            props, n_keep, cache[key] = ops.rpn_proposals_nchw(
                 list_cls, list_regs, anchors, k, info[1], info[2], self.proposal_min_size, self.nms_threshold,
                 self.num_post_nms, max_slices=self.topk_max_slices, rounds=self.nms_rounds,
-                workspace=getattr(self, "_path_ws", None))
+                workspace=cache.get(key))
             return props, n_keep
         scores, deltas = ops.rpn_flatten(list_cls, list_regs)               # rpn.py:56-57
         top_val, top_idx = ops.topk_desc(scores, k, max_slices=self.topk_max_slices)   # rpn.py:66-67

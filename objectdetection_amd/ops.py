@@ -507,6 +507,11 @@ def decode_clip_filter(anchors, deltas, top_idx, top_score, image_h, image_w, mi
 
 
 # --------------------------------------------------------------------------------------- K4 NMS
+# Pinned host words that kernels write directly (NmsRounds): never handed back to torch's pinned-memory cache, because a
+# launch that is still queued when its owner is dropped would then write into whatever tensor gets the block next.
+_PINNED_FOREVER = []
+
+
 class NmsRounds:
     """How far into the round-path NMS the caller's recent batches got, fed forward as the next call's launch bound
     (frcnn_nms_sorted_rounds_f32).  The kernels leave, per image, the count of 64-candidate blocks that had work (16
@@ -529,6 +534,7 @@ class NmsRounds:
         t = self._used.get(key)
         if t is None:
             t = torch.full((B,), self.UNKNOWN, dtype=torch.int32).pin_memory()
+            _PINNED_FOREVER.append(t)  # a few bytes per call site; see the note at _PINNED_FOREVER
             self._used[key] = t
             self._seen[key] = collections.deque(maxlen=self.history)
         return t

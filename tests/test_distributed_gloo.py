@@ -108,6 +108,18 @@ def test_bench_launcher_reports_a_failed_rank():
     assert "ranks exited with" in err
 
 
+def test_bench_launcher_does_not_wait_for_ranks_stuck_behind_a_dead_one():
+    """Only rank 1 dies (before the first collective); rank 0 sits in the barrier waiting for it.  The launcher
+    polls every child, kills the survivors and exits non-zero well before any collective timeout."""
+    import time
+    t0 = time.monotonic()
+    rc, lines, err = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--batch", "3", "--dry-run"],
+                                timeout=120, env={"BENCH_TEST_FAIL_RANK": "1"})
+    assert rc != 0 and not lines
+    assert "ranks exited with" in err and "3" in err
+    assert time.monotonic() - t0 < 90
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu_for_rehearsal():
     """The real kernels under the rank plumbing with a single GPU at hand: BENCH_REHEARSE_ON_ONE_GPU=1 puts both ranks

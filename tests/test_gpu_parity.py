@@ -1733,6 +1733,42 @@ def test_determinism(dev):
     assert torch.equal(i1, i2) and torch.equal(v1, v2)
 
 
+def test_rpn_proposals_from_two_streams_do_not_share_a_workspace(dev):
+    """One RPN module called alternately from two streams with different head outputs and no synchronisation in
+    between: each stream's calls keep their own intermediates (the one-call proposal half used to keep ONE
+    workspace on the module, which calls on different streams overwrote for each other)."""
+    from objectdetection_amd.RPN import RPN, AnchorGenerator
+    rng = np.random.default_rng(91)
+    info, fsz = (2, 600, 1000), [(37, 62)]
+    heads = []
+    for _ in range(2):
+        list_cls, list_regs = synth_head_outputs(rng, info[0], fsz)
+        heads.append(([T(c, dev) for c in list_cls], [T(r, dev) for r in list_regs]))
+    head = _FixedHead(*heads[0])
+    params = dict(anchor_generator=AnchorGenerator(), rpn_head=head, num_pre_nms=12000, num_post_nms=2000,
+                  nms_threshold=0.7, proposal_min_size=1e-3, pos_threshold=0.7, neg_threshold=0.3, num_sample=256,
+                  pos_fraction=0.5)
+    rpn = RPN(params).eval()
+    feats = [torch.zeros(info[0], 1, h, w, device=dev) for h, w in fsz]
+    ref = []
+    for c, r in heads:
+        head.c, head.r = c, r
+        p_, n_ = rpn.proposals_padded(info, feats)
+        torch.cuda.synchronize()
+        ref.append((p_.clone(), n_.clone()))
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    got = []
+    for it in range(6):
+        i = it & 1
+        head.c, head.r = heads[i]
+        with torch.cuda.stream(streams[i]):
+            got.append((i,) + tuple(rpn.proposals_padded(info, feats)))
+    torch.cuda.synchronize()
+    assert len(rpn._path_ws) >= 3  # the default stream's and one per side stream
+    for i, p_, n_ in got:
+        assert torch.equal(n_, ref[i][1]) and torch.equal(p_, ref[i][0])
+
+
 def test_two_stream_pipeline_matches_serial(dev):
     """ProposalRoIPipeline (two batches in flight on two streams) returns, bit for bit, what the same
     stages give when run one after the other on one stream -- over consecutive, different batches, so
