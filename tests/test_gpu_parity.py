@@ -1733,6 +1733,44 @@ def test_determinism(dev):
     assert torch.equal(i1, i2) and torch.equal(v1, v2)
 
 
+def test_config5_at_its_stated_batch_of_64(dev, oracle):
+    """BASELINE configs[4] at the batch it names (64 images, A = 200,907, 30,000 -> 2,000, four-level pooling with
+    C = 256: 6.4 GB of RoI features) -- too large for the CPU oracle as a whole, so: (a) the proposals of an image
+    inside the batch of 64 are, bit for bit, what the same image gives alone (whose parity with the oracle
+    test_rpn_forward_vs_oracle and test_rpn_proposals_one_call_matches_stages establish at this shape); (b) sampled
+    rows of the pooled features against the oracle, for both kernel families; (c) every image fills its 2,000 keeps."""
+    import bench
+    from objectdetection_amd import ops
+    B = 64
+    x = bench.config5_inputs(B, dev)
+    Himg, Wimg = x["Himg"], x["Wimg"]
+    props, n_keep, _ = ops.rpn_proposals_nchw(x["cls"], x["reg"], x["anchors"], 30000, Himg, Wimg, 1e-3, 0.7, 2000)
+    assert int(n_keep.min()) == 2000
+    picks = (0, 37, 63)
+    for b in picks:
+        p1, n1, _ = ops.rpn_proposals_nchw([c[b:b + 1].contiguous() for c in x["cls"]],
+                                           [r[b:b + 1].contiguous() for r in x["reg"]], x["anchors"], 30000, Himg, Wimg,
+                                           1e-3, 0.7, 2000)
+        assert int(n1[0]) == int(n_keep[b]) and torch.equal(p1[0], props[b])
+    feats = x["feats"][::-1]                                            # fine to coarse
+    pool = ops.MultiScaleRoIAlign(['1', '2', '3', '4'], (7, 7), 2)
+    fl, scales, k_min, k_max = pool._levels({str(i + 1): f for i, f in enumerate(feats)}, [(Himg, Wimg)])
+    cfg = ((7, 7), 2, tuple(float(s_) for s_ in scales), int(k_min), int(k_max))
+    rng = np.random.default_rng(64)
+    rows = {b: np.sort(rng.choice(2000, 24, replace=False)) for b in picks}
+    refs = {}
+    for b in picks:
+        refs[b], _ = oracle.multiscale_roi_align([f[b:b + 1].cpu().numpy() for f in feats],
+                                                 [props[b].cpu().numpy()[rows[b]]], [(Himg, Wimg)], (7, 7), 2)
+    for path in ("tiles", "cl"):
+        out, total = ops._roi_align_levels(cfg, props, n_keep, fl, path=path)
+        assert int(total) == B * 2000
+        for b in picks:
+            got = out[torch.as_tensor(b * 2000 + rows[b], device=dev)].cpu().numpy()
+            np.testing.assert_allclose(got, refs[b], rtol=RTOL, atol=2e-5, err_msg="%s image %d" % (path, b))
+        del out
+
+
 def test_rpn_proposals_from_two_streams_do_not_share_a_workspace(dev):
     """One RPN module called alternately from two streams with different head outputs and no synchronisation in
     between: each stream's calls keep their own intermediates (the one-call proposal half used to keep ONE
