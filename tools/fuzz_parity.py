@@ -149,6 +149,42 @@ def fuzz_roi_align(rng):
     return f"img={img} levels={fsz} B={B} C={C} n={n}"
 
 
+def fuzz_roi_align_cl(rng):
+    """MultiScaleRoIAlign through csrc/roi_cl.hip (lanes = channels): C a multiple of 64, maps channels-last (read in
+    place) or NCHW (copied first), both against the oracle and bit for bit against each other."""
+    from objectdetection_amd import ops
+    img, fsz = pyramid(rng)
+    B = int(rng.integers(1, 4))
+    C = int(rng.choice([64, 64, 128, 192]))
+    if sum(h * w for h, w in fsz) * C * B > 40e6:   # keeps the oracle's share of a draw small
+        C, B = 64, min(B, 2)
+    n = [int(rng.choice([0, 1, 5, 64, 65, int(rng.integers(1, 200))])) for _ in range(B)]
+    if sum(n) == 0:
+        n[0] = 3
+    feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for h, w in fsz]
+    props = [random_boxes(rng, k, img[1], img[0]) if k else np.zeros((0, 4), np.float32) for k in n]
+    names = [str(i + 1) for i in range(len(fsz))]
+    ref, _ = orc.multiscale_roi_align(feats, props, [img], (7, 7), 2)
+    pool = ops.MultiScaleRoIAlign(names, (7, 7), 2)
+    fd, scales, k_min, k_max = pool._levels({nm: T(f, dev) for nm, f in zip(names, feats)}, [img])
+    cfg = ((7, 7), 2, tuple(float(s_) for s_ in scales), int(k_min), int(k_max))
+    P = max(n)
+    padded = np.zeros((B, P, 4), np.float32)
+    for b in range(B):
+        padded[b, :n[b]] = props[b]
+    pd, cd = T(padded, dev), T(np.asarray(n, np.int32), dev, torch.int32)
+    cl_first = bool(rng.random() < 0.5)
+    outs = []
+    for cl_maps in (cl_first, not cl_first):
+        maps = [f.contiguous(memory_format=torch.channels_last) for f in fd] if cl_maps else fd
+        out, total = ops._roi_align_levels(cfg, pd, cd, maps, path="cl")
+        assert int(total) == sum(n)
+        np.testing.assert_allclose(out[:sum(n)].cpu().numpy(), ref, rtol=RTOL, atol=1e-5)
+        outs.append(out[:sum(n)].clone())
+    assert torch.equal(outs[0], outs[1])
+    return f"img={img} levels={fsz} B={B} C={C} n={n}"
+
+
 def fuzz_roi_backward(rng):
     img, fsz = pyramid(rng)
     B = int(rng.integers(1, 4))
@@ -275,7 +311,7 @@ def fuzz_targets(rng):
     return f"B={B} A={A} M={M} ms={ms} per_image={per_image} thr=({neg},{pos})"
 
 
-OPS = {"targets": fuzz_targets, "rpn": fuzz_rpn, "topk": fuzz_topk, "nms": fuzz_nms, "roi_align": fuzz_roi_align, "roi_backward": fuzz_roi_backward,
+OPS = {"targets": fuzz_targets, "rpn": fuzz_rpn, "topk": fuzz_topk, "nms": fuzz_nms, "roi_align": fuzz_roi_align, "roi_align_cl": fuzz_roi_align_cl, "roi_backward": fuzz_roi_backward,
        "roi_pool": fuzz_roi_pool}
 
 
