@@ -709,6 +709,52 @@ struct Weights4 {
 // One lane per box_1 row; the image's ground-truth boxes (+ areas) are staged in LDS tiles and
 // swept by every lane (wave-uniform LDS address => broadcast reads).  Running max follows
 // torch.max(dim=1): replace when !(v <= best); the first NaN wins and freezes the row.
+//
+// Round 3: no division per pair.  While every box of the wave and of the tile is "regular" (area in
+// (1e-6, 1e12): finite, no 0/0, no product that under- or overflows) the running max is kept as the PAIR
+// (inter, union) of the best box, and "is fl(i/u) > fl(bi/bu)" is decided by cross-multiplication,
+// d = i*bu - bi*u: when |d| > 2^-20 (i*bu + bi*u) the exact quotients differ by more than 2^-21 relative -- four
+// units in the last place -- so their roundings are ordered like d's sign; when both products are zero both
+// quotients are +0 (no replacement); anything else (ties between equal boxes, one pair in ~2^20 otherwise) is
+// redone with the two IEEE divisions, which IS the definition.  The decision is taken for FOUR boxes at a
+// time (one wave-uniform branch per group).  One division per row at the end gives the maximum itself.
+// Irregular boxes (degenerate, NaN, huge) take the loop of rounds 1-2, division per pair, unchanged.
+#define IOU_REG_LO 1e-6f
+#define IOU_REG_HI 1e12f
+
+struct IouBest { // running max of one row in the regular loop
+    float bi, bu; // intersection and union of the best box so far
+    int arg;
+};
+
+// The operations of frcnn_iou, in its order (utils.py:114-119), for REGULAR boxes: v_max_f32 / v_min_f32 return what
+// the reference's compare-and-select does whenever neither operand is NaN and the two are not zeros of opposite sign
+// (regular boxes hold no NaN and no -0: iou_regular), and a clamped difference of such operands is never -0.
+__device__ __forceinline__ void iou_terms(const float4 &a, float aarea, const float4 &g, float garea, float &inter,
+                                          float &uni)
+{
+    const float ltx = frcnn_vmax(a.x, g.x), lty = frcnn_vmax(a.y, g.y);
+    const float rbx = frcnn_vmin(a.z, g.z), rby = frcnn_vmin(a.w, g.w);
+    const float jw = frcnn_vmax(rbx - ltx, 0.0f), jh = frcnn_vmax(rby - lty, 0.0f);
+    inter = jw * jh;
+    uni = (aarea + garea) - inter;
+}
+
+__device__ __forceinline__ bool iou_regular(const float4 &b, float area)
+{
+    const bool neg_zero = __float_as_uint(b.x) == 0x80000000u || __float_as_uint(b.y) == 0x80000000u ||
+                          __float_as_uint(b.z) == 0x80000000u || __float_as_uint(b.w) == 0x80000000u;
+    return area > IOU_REG_LO && area < IOU_REG_HI && !neg_zero;
+}
+
+__device__ __forceinline__ void iou_best_exact(IouBest &s, float inter, float uni, int j)
+{
+    const bool take = (inter / uni) > (s.bi / s.bu); // regular boxes: no NaN, so !(v <= best) is v > best
+    s.bi = take ? inter : s.bi;
+    s.bu = take ? uni : s.bu;
+    s.arg = take ? j : s.arg;
+}
+
 __global__ void __launch_bounds__(256)
 iou_label_encode_kernel(const float4 *__restrict__ box1, long long box1_batch_stride4,
                         const float4 *__restrict__ box2, const int32_t *__restrict__ m_per_image,
@@ -723,21 +769,70 @@ iou_label_encode_kernel(const float4 *__restrict__ box1, long long box1_batch_st
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int m = m_per_image ? m_per_image[b] : m_max;
     const float4 *gt = box2 + (long long)b * m_max;
-    float4 a = make_float4(0, 0, 0, 0);
+    float4 a = make_float4(0.0f, 0.0f, 1.0f, 1.0f); // lanes past the end: a regular box, never written back
     if (i < N) a = box1[(long long)b * box1_batch_stride4 + i];
     float aarea = frcnn_area(a.x, a.y, a.z, a.w);
     float best = 0.0f;
     int arg = 0;
     bool frozen = false;
+    IouBest rb = {0.0f, 1.0f, 0};
+    // wave-uniform: does this wave still run the division-free loop?  (Once a tile sends it to the generic loop it
+    // stays there: the generic state is the value, not the pair.)
+    bool regular = __all(iou_regular(a, aarea));
     for (int j0 = 0; j0 < m; j0 += IOU_TILE_M) {
         int jn = min(IOU_TILE_M, m - j0);
         __syncthreads();
+        bool g_reg = true;
         if ((int)threadIdx.x < jn) {
             float4 g = gt[j0 + threadIdx.x];
+            const float ga = frcnn_area(g.x, g.y, g.z, g.w);
             s_box[threadIdx.x] = g;
-            s_area[threadIdx.x] = frcnn_area(g.x, g.y, g.z, g.w);
+            s_area[threadIdx.x] = ga;
+            g_reg = iou_regular(g, ga);
         }
-        __syncthreads();
+        const bool tile_reg = __syncthreads_and(g_reg) != 0;
+        if (regular && !tile_reg) { // leave the pair form for good: the value of the best box so far
+            regular = false;
+            if (j0 > 0) {
+                best = rb.bi / rb.bu;
+                arg = rb.arg;
+            }
+        }
+        if (regular) {
+            int j = 0;
+            if (j0 == 0) { // the first box is taken whatever its value
+                iou_terms(a, aarea, s_box[0], s_area[0], rb.bi, rb.bu);
+                rb.arg = 0;
+                j = 1;
+            }
+            for (; j + 4 <= jn; j += 4) {
+                const IouBest saved = rb;
+                float in4[4], un4[4];
+                unsigned long long unsure = 0; // lanes whose decision for one of the four boxes is inside the band
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    iou_terms(a, aarea, s_box[j + u], s_area[j + u], in4[u], un4[u]);
+                    const float p1 = in4[u] * rb.bu, p2 = rb.bi * un4[u];
+                    const float d = p1 - p2, sum = p1 + p2;
+                    unsure |= __ballot(fabsf(d) <= sum * 9.5367431640625e-07f) & __ballot(sum > 0.0f);
+                    const bool take = d > 0.0f;
+                    rb.bi = take ? in4[u] : rb.bi;
+                    rb.bu = take ? un4[u] : rb.bu;
+                    rb.arg = take ? j0 + j + u : rb.arg;
+                }
+                if (__builtin_expect(unsure != 0, 0)) { // wave-uniform: the group again, by the definition
+                    rb = saved;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) iou_best_exact(rb, in4[u], un4[u], j0 + j + u);
+                }
+            }
+            for (; j < jn; ++j) {
+                float inter, uni;
+                iou_terms(a, aarea, s_box[j], s_area[j], inter, uni);
+                iou_best_exact(rb, inter, uni, j0 + j);
+            }
+            continue;
+        }
         for (int j = 0; j < jn; ++j) {
             float4 g = s_box[j];
             float v = frcnn_iou(a.x, a.y, a.z, a.w, aarea, g.x, g.y, g.z, g.w, s_area[j]);
@@ -749,6 +844,10 @@ iou_label_encode_kernel(const float4 *__restrict__ box1, long long box1_batch_st
                 frozen = (v != v);
             }
         }
+    }
+    if (regular && m > 0) {
+        best = rb.bi / rb.bu;
+        arg = rb.arg;
     }
     if (i >= N) return;
     long long o = (long long)b * N + i;

@@ -1,6 +1,6 @@
 """Small driver for rocprofv3 runs: exercises one stage of the hot path a few times.
 
-    python tools/prof_kernels.py roi|nms|topk [reps]
+    python tools/prof_kernels.py roi|nms|topk|targets [reps]
 """
 import os
 import sys
@@ -31,9 +31,16 @@ def main():
     boxes, _, _, count = ops.decode_clip_filter(anchors, deltas, top_idx, top_val, bench.IMG_H, bench.IMG_W, bench.MIN_SIZE)
     keep, n_keep = ops.nms_sorted(boxes, count, bench.NMS_THR, bench.POST_NMS)
     props = ops.gather_boxes(boxes, keep, n_keep)
+    if what == "targets":  # K5 at BASELINE configs[2]: 16 x 20,646 anchors x 100 boxes
+        g = torch.Generator().manual_seed(3)
+        wh = torch.rand(B, 100, 2, generator=g) * 240 + 16
+        xy = torch.rand(B, 100, 2, generator=g) * (torch.tensor([bench.IMG_W, bench.IMG_H]) - wh)
+        gt = torch.cat([xy, xy + wh], 2).to(dev)
     torch.cuda.synchronize()
     for _ in range(reps):
-        if what == "roi":
+        if what == "targets":
+            ops.iou_label_encode(anchors, gt, None, 0.3, 0.7)
+        elif what == "roi":
             path.pool.forward_padded({'1': feat}, props, n_keep, [(bench.IMG_H, bench.IMG_W)])
         elif what == "nms":
             ops.nms_sorted(boxes, count, bench.NMS_THR, bench.POST_NMS)
