@@ -27,10 +27,7 @@
 #ifndef RCL_THREADS
 #define RCL_THREADS 64 // one wave per workgroup: a wave that has finished its RoIs frees its registers and LDS at once
 #endif
-#ifndef RCL_CPL
-#define RCL_CPL 1 // channels per lane: 1 = a wave item is (RoI, 64 channels), 2 = (RoI, 128 channels) with packed sums
-#endif
-#define RCL_CH (64 * RCL_CPL) // channels per wave item
+#define RCL_CH 64 // channels per wave item: a lane is a channel
 #define RCL_WAVES (RCL_THREADS / 64)
 #define RCL_CHUNK_DEFAULT 2 // RoIs per workgroup (<= 64: a chunk's codes and boxes travel one per lane)
 #define RCL_MAX_UNITS 16
@@ -40,7 +37,7 @@
 #define RCL_ZERO_LV 7 // level code of a RoI that no level takes (NaN area): its rows are zeros
 #define RCL_PREP_THREADS 1024
 #ifndef RCL_WAVES_PER_EU
-#define RCL_WAVES_PER_EU (RCL_CPL == 2 ? 2 : 4) // 256 / 128 registers per lane
+#define RCL_WAVES_PER_EU 4 // 128 registers per lane
 #endif
 
 struct ClLevel {
@@ -91,7 +88,7 @@ __device__ __forceinline__ void cl_copy_tile(const ClCopy &T, int C, int tile, i
     for (int k = 0; k < 16; ++k) s_t[k * 4 + q][lane] = v[k];
     __syncthreads();
     // destination: (B, C / RCL_CH, H * W, RCL_CH) -- the slice of an image that a wave item reads is one contiguous block
-    float *d = dst + (((long long)b * (C / RCL_CH) + cg / RCL_CPL) * HW + px0) * RCL_CH + (cg % RCL_CPL) * 64;
+    float *d = dst + (((long long)b * (C / RCL_CH) + cg) * HW + px0) * RCL_CH;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int px = k * 4 + q;
@@ -188,6 +185,94 @@ roi_cl_sort_kernel(ClLevels L, const float4 *__restrict__ props, const int32_t *
     }
 }
 
+__device__ __forceinline__ float rcl_readlane(float v, int lane)
+{
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
+
+// ---- per-RoI set-up, by the lanes of the wave in parallel ---------------------------------------------------------
+// Lanes 0..27 take the 7 x 4 x taps (weight, cell), lanes 32..45 the 14 row samples; out come the ascending list of
+// the <= 28 rows the samples touch (one row per lane) and the weight of each list row in each of the 7 bin rows.
+// (Computing these once per RoI in a launch of its own and loading them here -- 1,152 bytes per RoI, x taps by scalar
+// loads -- was built and measured: 0.986 against 0.944 ms at config 5; the table's load latency at the head of every
+// item costs more than the ~450 vector instructions it replaces.)
+#define RCL_RING_CELLS 16
+struct ClSetup {
+    int nrows;   // rows in the list (wave-uniform)
+    bool x3;     // every bin's two x samples merge into three taps (wave-uniform)
+    int c0, c1;  // first and last cell the x taps read (wave-uniform)
+    int v_cell;  // lane j < 28: the cell of tap j = (bin j / 4, tap j % 4)
+    float v_xw;  //              and its weight
+    int v_rows;  // lane k < nrows: row k of the list
+    float v_wy[7]; //            and its weight in every bin row (zeros from lane nrows on)
+};
+
+__device__ __forceinline__ ClSetup rcl_setup(float4 box, float scale, int H, int W, int lane)
+{
+    ClSetup S;
+    const float4 rec = roi_record(box, scale);
+    const bool is_y = lane >= 32;
+    const int idx = lane & 31;
+    const int p = min(is_y ? idx >> 1 : idx >> 2, 6);
+    AxisSample sm[2];
+    tile_bin_samples(is_y ? rec.y : rec.x, is_y ? rec.w : rec.z, p, is_y ? H : W, sm);
+    const bool x3 = (__ballot(axis_mergeable(sm[0], sm[1]) || is_y || idx >= 28) == ~0ull);
+    const AxisTaps tx = x3 ? axis_taps3(sm[0], sm[1], 1.0f, W) : axis_taps4(sm[0], sm[1], 1.0f);
+    const AxisSample sy = (idx & 1) ? sm[1] : sm[0];
+    // Row samples (lanes 32..45): the sample's last row b (its high row, or the clamped row H - 1 alone) with
+    // weight wh, and the row above it with weight wl when it takes part.
+    const bool valid = is_y && idx < 14 && sy.ok;
+    const bool use_lo = sy.hi != sy.lo;
+    const int b_row = valid ? sy.hi : -8;
+    const float s_wl = (valid && use_lo) ? sy.wlo * 0.25f : 0.0f;
+    const float s_wh = valid ? (use_lo ? sy.whi : sy.wlo) * 0.25f : 0.0f;
+    // the ascending list of rows the samples touch: a sample appends the rows the one before it did not
+    const int prev_b = __shfl_up(b_row, 1);
+    const int pb = idx > 0 ? prev_b : -8; // (the valid samples are consecutive lanes)
+    const bool new_a = valid && use_lo && b_row - 1 > pb;
+    const bool new_b = valid && b_row > pb;
+    const unsigned long long mask_a = __ballot(new_a), mask_b = __ballot(new_b);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int pos_a = __popcll(mask_a & below) + __popcll(mask_b & below);
+    const int pos_b = pos_a + (new_a ? 1 : 0);
+#ifdef RCL_EXP_NOROWS
+    S.nrows = 0 * (__popcll(mask_a) + __popcll(mask_b)); // experiment: set-up and epilogue alone
+#else
+    S.nrows = __popcll(mask_a) + __popcll(mask_b);
+#endif
+    const int ra = __builtin_amdgcn_ds_permute((new_a ? pos_a : 63) * 4, b_row); // (row + 1) of b_row - 1
+    const int rb = __builtin_amdgcn_ds_permute((new_b ? pos_b : 63) * 4, b_row + 1);
+#ifdef RCL_EXP_ONEROW
+    S.v_rows = 0 * max(max(ra, rb) - 1, 0); // experiment: every row fetch hits the same cells
+#else
+    S.v_rows = max(max(ra, rb) - 1, 0);
+#endif
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) S.v_wy[ph] = 0.0f;
+#pragma unroll
+    for (int sidx = 0; sidx < 14; ++sidx) {
+        const int sb = __builtin_amdgcn_readlane(b_row, 32 + sidx);
+        const float wl = rcl_readlane(s_wl, 32 + sidx), wh = rcl_readlane(s_wh, 32 + sidx);
+        const float w = (S.v_rows == sb ? wh : 0.0f) + (S.v_rows == sb - 1 ? wl : 0.0f);
+        S.v_wy[sidx >> 1] += lane < S.nrows ? w : 0.0f;
+    }
+    const int t = idx & 3;
+    S.v_cell = t == 0 ? tx.idx[0] : t == 1 ? tx.idx[1] : t == 2 ? tx.idx[2] : tx.idx[3];
+    S.v_xw = t == 0 ? tx.w[0] : t == 1 ? tx.w[1] : t == 2 ? tx.w[2] : tx.w[3];
+    // the span of the cells the x taps read (a merged bin's fourth tap is not read)
+    const bool tap_read = lane < 28 && (t < 3 || !x3);
+    int cmin = tap_read ? S.v_cell : 0x7fffffff, cmax = tap_read ? S.v_cell : -1;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        cmin = min(cmin, __shfl_xor(cmin, d));
+        cmax = max(cmax, __shfl_xor(cmax, d));
+    }
+    S.c0 = __builtin_amdgcn_readfirstlane(cmin);
+    S.c1 = __builtin_amdgcn_readfirstlane(cmax);
+    S.x3 = x3;
+    return S;
+}
+
 // One 64-channel x 64-pixel tile per workgroup.
 __global__ void __launch_bounds__(256)
 nchw_to_cl_kernel(ClCopy T, int C, int tiles)
@@ -197,16 +282,7 @@ nchw_to_cl_kernel(ClCopy T, int C, int tiles)
 
 // ---- the main kernel -------------------------------------------------------------------------------------------
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-#if RCL_CPL == 2
-typedef f32x2 rcl_vec; // a lane's channels: `lane` (.x) and `lane + 64` (.y) of the wave's 128
-#else
 typedef float rcl_vec;
-#endif
-
-__device__ __forceinline__ float rcl_readlane(float v, int lane)
-{
-    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
-}
 
 // A lane's channels of one cell, one dword load of 256 contiguous bytes per 64 channels.  (An 8-byte load per lane
 // moves the same bytes through the vector cache at half the rate: 17 cache accesses per 512-byte wave load against 4
@@ -215,22 +291,23 @@ __device__ __forceinline__ rcl_vec rcl_loadv(__amdgpu_buffer_rsrc_t rsrc, int vo
 {
 #ifdef RCL_EXP_NOLOAD
     return rcl_vec(__uint_as_float(voff + soff)); // experiment: arithmetic and stores without the loads
-#elif RCL_CPL == 2
-    f32x2 r;
-    r.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
-    r.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 256, soff, 0));
-    return r;
 #else
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
 #endif
 }
 
+typedef float rcl_f32x4 __attribute__((ext_vector_type(4)));
+// The output is written once and never read here: `nt` stores (global_store_dwordx4 ... nt), 0.887 against 0.911 ms at
+// config 5 with plain ones; `sc1` / `sc0 sc1` (write-through, line dropped from L2) measured like plain.
 __device__ __forceinline__ void rcl_store(float4 *p, float4 v)
 {
+    const rcl_f32x4 q = {v.x, v.y, v.z, v.w};
 #ifdef RCL_EXP_NOSTORE
-    if (v.x == 1234.5f) *p = v; // experiment: everything but the store stream
+    if (v.x == 1234.5f) *reinterpret_cast<rcl_f32x4 *>(p) = q; // experiment: everything but the store stream
+#elif defined(RCL_EXP_STORE_PLAIN)
+    *reinterpret_cast<rcl_f32x4 *>(p) = q;
 #else
-    *p = v;
+    __builtin_nontemporal_store(q, reinterpret_cast<rcl_f32x4 *>(p));
 #endif
 }
 
@@ -240,24 +317,14 @@ __device__ __forceinline__ void rcl_store(float4 *p, float4 v)
 __device__ __forceinline__ void rcl_fma(rcl_vec &acc, uint64_t w, rcl_vec t)
 {
     const uint32_t ws = (uint32_t)w;
-#if RCL_CPL == 2
-    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc.x) : "s"(ws), "v"(t.x));
-    asm("v_fmac_f32 %0, %1, %2" : "+v"(acc.y) : "s"(ws), "v"(t.y));
-#else
     asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(ws), "v"(t));
-#endif
 }
 
 __device__ __forceinline__ rcl_vec rcl_mul(uint64_t w, rcl_vec t)
 {
     const uint32_t ws = (uint32_t)w;
     rcl_vec r;
-#if RCL_CPL == 2
-    asm("v_mul_f32 %0, %1, %2" : "=v"(r.x) : "s"(ws), "v"(t.x));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(r.y) : "s"(ws), "v"(t.y));
-#else
     asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "s"(ws), "v"(t));
-#endif
     return r;
 }
 
@@ -293,20 +360,6 @@ __device__ __forceinline__ void rcl_reduce(rcl_vec (&T)[7], const rcl_vec (&v)[7
 __device__ __forceinline__ void rcl_add_row(rcl_vec *a, uint32_t w, const rcl_vec (&T)[7])
 {
     uint32_t tmp;
-#if RCL_CPL == 2
-    asm("s_and_b32 %14, %15, 0x7fffffff\n\t"
-        "s_cbranch_scc0 .Lrcl_skip%=\n\t"
-        "v_fmac_f32 %0, %15, %16\n\tv_fmac_f32 %1, %15, %17\n\tv_fmac_f32 %2, %15, %18\n\tv_fmac_f32 %3, %15, %19\n\t"
-        "v_fmac_f32 %4, %15, %20\n\tv_fmac_f32 %5, %15, %21\n\tv_fmac_f32 %6, %15, %22\n\tv_fmac_f32 %7, %15, %23\n\t"
-        "v_fmac_f32 %8, %15, %24\n\tv_fmac_f32 %9, %15, %25\n\tv_fmac_f32 %10, %15, %26\n\tv_fmac_f32 %11, %15, %27\n\t"
-        "v_fmac_f32 %12, %15, %28\n\tv_fmac_f32 %13, %15, %29\n"
-        ".Lrcl_skip%=:"
-        : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[1].x), "+v"(a[1].y), "+v"(a[2].x), "+v"(a[2].y), "+v"(a[3].x), "+v"(a[3].y),
-          "+v"(a[4].x), "+v"(a[4].y), "+v"(a[5].x), "+v"(a[5].y), "+v"(a[6].x), "+v"(a[6].y), "=&s"(tmp)
-        : "s"(w), "v"(T[0].x), "v"(T[0].y), "v"(T[1].x), "v"(T[1].y), "v"(T[2].x), "v"(T[2].y), "v"(T[3].x), "v"(T[3].y),
-          "v"(T[4].x), "v"(T[4].y), "v"(T[5].x), "v"(T[5].y), "v"(T[6].x), "v"(T[6].y)
-        : "scc");
-#else
     asm("s_and_b32 %7, %8, 0x7fffffff\n\t"
         "s_cbranch_scc0 .Lrcl_skip%=\n\t"
         "v_fmac_f32 %0, %8, %9\n\tv_fmac_f32 %1, %8, %10\n\tv_fmac_f32 %2, %8, %11\n\tv_fmac_f32 %3, %8, %12\n\t"
@@ -315,11 +368,10 @@ __device__ __forceinline__ void rcl_add_row(rcl_vec *a, uint32_t w, const rcl_ve
         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "=&s"(tmp)
         : "s"(w), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(T[4]), "v"(T[5]), "v"(T[6])
         : "scc");
-#endif
 }
 
 #ifndef RCL_DEPTH
-#define RCL_DEPTH (RCL_CPL == 2 ? 2 : 1)
+#define RCL_DEPTH 1
 #endif
 #define RCL_OOB 0x40000000 // added to a lane's byte offset: beyond every map, so the buffer load returns 0 unread
 
@@ -344,14 +396,8 @@ __device__ __forceinline__ void rcl_row(rcl_vec (&acc)[49], rcl_vec (&Lb)[7 * NX
 
 template <int NX>
 __device__ __forceinline__ void rcl_item(rcl_vec (&acc)[49], __amdgpu_buffer_rsrc_t rsrc, int lane8, int row_bytes,
-                                         int v_cell, float v_xw, int v_rows, const float (&v_wy)[7], int nrows)
+                                         const uint64_t (&wx)[28], int v_rows, const float (&v_wy)[7], int nrows)
 {
-    uint64_t wx[28];
-#pragma unroll
-    for (int j = 0; j < 28; ++j)
-        wx[j] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(v_cell, j) << 32) |
-                (uint32_t)__builtin_amdgcn_readlane(__float_as_uint(v_xw), j);
-    if (nrows <= 0) return;
     // RCL_DEPTH rows in flight: a row's loads are issued that many rows ahead, always (past the list they go out of
     // range and return zeros unread), so that the number of loads behind the one a contraction waits for is known
     // statically.  Rows in pairs with one exit: behind an odd list the second row of the last pair is a null row (its
@@ -370,11 +416,87 @@ __device__ __forceinline__ void rcl_item(rcl_vec (&acc)[49], __amdgpu_buffer_rsr
 #endif
 }
 
+// ---- rows through LDS: 16-byte fills, every cell of a row fetched once ------------------------------------------
+// The vector cache serves a wave's dword loads at ~35 bytes per clock and CU and its dwordx4 loads at ~72
+// (tools/ubench/vmem_valu_overlap.hip), and the taps of neighbouring bins overlap (21-28 taps on 9-16 distinct cells).
+// When the cells a RoI touches in a row span at most RCL_RING_CELLS, the row is therefore fetched as that many
+// CONTIGUOUS cells by four `buffer_load_dwordx4 ... lds` (LDS-DMA: 1 KiB = four 64-channel cells of the blocked copy per
+// instruction, no registers) into a wave-private two-slot ring, and the 21-28 taps are ds_read_b32 from it (lane =
+// channel).  The fills of row k + 1 are in flight while row k is contracted; `s_waitcnt vmcnt(4)` is placed by hand
+// (fills, like every vector memory operation, retire in order).  68 cycles per row and CU in tools/ubench/lds_dma.hip
+// against 21 x 7.7 = 162 for the register loads.
+#define RCL_SLOT_FLOATS (RCL_RING_CELLS * 64)
+typedef __attribute__((address_space(3))) void rcl_lds_void;
+
+// One fill = four cells: lane l brings bytes [16 (l % 16), +16) of cell l / 16 (vlane = that cell's and piece's byte
+// offset: cells are cell_bytes apart, 256 in the blocked copy where a fill is one contiguous KiB); in LDS the four
+// cells are contiguous whatever the layout.
+__device__ __forceinline__ void rcl_fill_row(__amdgpu_buffer_rsrc_t rsrc, float *slot, int vlane, int off, int cell_bytes)
+{
+#pragma unroll
+    for (int d = 0; d < RCL_RING_CELLS / 4; ++d)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (rcl_lds_void *)(slot + d * 256), 16, vlane, off + d * 4 * cell_bytes, 0, 0);
+}
+
+template <int NX>
+__device__ __forceinline__ void rcl_ring_row(float (&acc)[49], const float *slot, float *refill, __amdgpu_buffer_rsrc_t rsrc,
+                                             int vlane, int row_bytes, int cell_bytes, int c0_bytes, const int (&vaddr)[7 * NX],
+                                             const uint64_t (&wx)[28], int v_rows, const float (&v_wy)[7], int k, int nrows)
+{
+    uint32_t wy[7];
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) wy[ph] = __builtin_amdgcn_readlane(__float_as_uint(v_wy[ph]), min(k, 63));
+    // this row's four fills have landed once at most the four of the next row are outstanding
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    float v[7 * NX];
+#pragma unroll
+    for (int j = 0; j < 7 * NX; ++j) v[j] = *(const float *)((const char *)slot + vaddr[j]);
+    float T[7];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) T[p] = rcl_mul(wx[p * 4], v[p * NX]);
+#pragma unroll
+    for (int t = 1; t < NX; ++t)
+#pragma unroll
+        for (int p = 0; p < 7; ++p) rcl_fma(T[p], wx[p * 4 + t], v[p * NX + t]);
+    // the taps are in registers (T depends on them): the slot may be refilled with the row two further on
+    const int kn = k + 2;
+    rcl_fill_row(rsrc, refill, vlane + (kn < nrows ? 0 : RCL_OOB),
+                 __builtin_amdgcn_readlane(v_rows, min(kn, 63)) * row_bytes + c0_bytes, cell_bytes);
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) rcl_add_row(&acc[ph * 7], wy[ph], T);
+}
+
+template <int NX>
+__device__ __forceinline__ void rcl_item_ring(float (&acc)[49], __amdgpu_buffer_rsrc_t rsrc, int lane, int row_bytes,
+                                              int cell_bytes, int c0, const uint64_t (&wx)[28], int v_rows,
+                                              const float (&v_wy)[7], int nrows, float *ring)
+{
+    // here the high word of wx[j] is 256 x tap j's cell: where the cell sits in a ring slot, c0's 256 bytes on
+    int vaddr[7 * NX];
+#pragma unroll
+    for (int p = 0; p < 7; ++p)
+#pragma unroll
+        for (int t = 0; t < NX; ++t) vaddr[p * NX + t] = ((int)(wx[p * 4 + t] >> 32) - c0 * 256) + lane * 4;
+    const int vlane = (lane >> 4) * cell_bytes + (lane & 15) * 16;
+    const int c0_bytes = c0 * cell_bytes;
+    float *s0 = ring, *s1 = ring + RCL_SLOT_FLOATS;
+    rcl_fill_row(rsrc, s0, vlane, __builtin_amdgcn_readlane(v_rows, 0) * row_bytes + c0_bytes, cell_bytes);
+    rcl_fill_row(rsrc, s1, vlane + (1 < nrows ? 0 : RCL_OOB), __builtin_amdgcn_readlane(v_rows, 1) * row_bytes + c0_bytes,
+                 cell_bytes);
+    for (int k = 0; k < nrows; k += 2) {
+        rcl_ring_row<NX>(acc, s0, s0, rsrc, vlane, row_bytes, cell_bytes, c0_bytes, vaddr, wx, v_rows, v_wy, k, nrows);
+        rcl_ring_row<NX>(acc, s1, s1, rsrc, vlane, row_bytes, cell_bytes, c0_bytes, vaddr, wx, v_rows, v_wy, k + 1, nrows);
+    }
+    // the (out-of-range) fills issued behind the list still write the ring: it is reused by the epilogue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 __global__ void __launch_bounds__(RCL_THREADS) __attribute__((amdgpu_waves_per_eu(RCL_WAVES_PER_EU, RCL_WAVES_PER_EU)))
 roi_align_cl_kernel(ClLevels L, int C, int cgroups, int blocked, int chunks, int chunk_rois, int padded,
                     const ClRec *__restrict__ recs, int B, float *__restrict__ out)
 {
-    __shared__ float s_out[RCL_WAVES][(RCL_CPL == 2 ? 64 : 32) * 49];
+    __shared__ __attribute__((aligned(1024))) float s_out[RCL_WAVES][2 * RCL_SLOT_FLOATS]; // row ring; the epilogue reuses it
+    static_assert(2 * RCL_SLOT_FLOATS >= 32 * 49, "the epilogue's 32 x 49 floats fit the ring");
     // Blocks i and i + 8 share an XCD (observed dispatch order; speed only).  An XCD takes whole (image, channel
     // group) pairs, one after the other, and inside a pair the chunks in unit order.
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -394,12 +516,11 @@ roi_align_cl_kernel(ClLevels L, int C, int cgroups, int blocked, int chunks, int
     const int n = __popcll(__ballot(r.code >= 0)); // the valid records are the chunk's first ones
     float *sw = s_out[wave];
     for (int i = wave; i < n; i += RCL_WAVES) {
-        const int code = __builtin_amdgcn_readlane(r.code, i);
-        const int lv = code >> 24;
         const int out_row = __builtin_amdgcn_readlane(r.out_row, i);
+        float *o = out + ((long long)out_row * C + g * RCL_CH) * 49;
+        const int lv = __builtin_amdgcn_readlane(r.code, i) >> 24;
         const float4 box = make_float4(rcl_readlane(r.box.x, i), rcl_readlane(r.box.y, i), rcl_readlane(r.box.z, i),
                                        rcl_readlane(r.box.w, i));
-        float *o = out + ((long long)out_row * C + g * RCL_CH) * 49;
         // the sums start at zero here and are only ever updated in place (rcl_fma): one set of registers on every path
         rcl_vec acc[49];
 #pragma unroll
@@ -416,87 +537,43 @@ roi_align_cl_kernel(ClLevels L, int C, int cgroups, int blocked, int chunks, int
                 W = in ? L.l[l].W : W;
                 scale = in ? L.l[l].scale : scale;
             }
-            const float4 rec = roi_record(box, scale);
-            // the lane's table entries
-            const bool is_y = lane >= 32;
-            const int idx = lane & 31;
-            const int p = min(is_y ? idx >> 1 : idx >> 2, 6);
-            AxisSample sm[2];
-            tile_bin_samples(is_y ? rec.y : rec.x, is_y ? rec.w : rec.z, p, is_y ? H : W, sm);
-            const bool x3 = (__ballot(axis_mergeable(sm[0], sm[1]) || is_y || idx >= 28) == ~0ull);
-            const AxisTaps tx = x3 ? axis_taps3(sm[0], sm[1], 1.0f, W) : axis_taps4(sm[0], sm[1], 1.0f);
-            // blocked: (B, C / 128, H, W, 128), the copy this library makes; else (B, H, W, C) read in place
+            const ClSetup S = rcl_setup(box, scale, H, W, lane);
+            const int nrows = S.nrows, c0 = S.c0;
+            const bool x3 = S.x3;
+            // blocked: (B, C / 64, H, W, 64), the copy this library makes; else (B, H, W, C) read in place
             const int cell_bytes = blocked ? RCL_CH * 4 : C * 4;
-            const AxisSample sy = (idx & 1) ? sm[1] : sm[0];
-            // Row samples (lanes 32..45): the sample's last row b (its high row, or the clamped row H - 1 alone) with
-            // weight wh, and the row above it with weight wl when it takes part.
-            const bool valid = is_y && idx < 14 && sy.ok;
-            const bool use_lo = sy.hi != sy.lo;
-            const int b_row = valid ? sy.hi : -8;
-            const float s_wl = (valid && use_lo) ? sy.wlo * 0.25f : 0.0f;
-            const float s_wh = valid ? (use_lo ? sy.whi : sy.wlo) * 0.25f : 0.0f;
-            // the ascending list of rows the samples touch: a sample appends the rows the one before it did not
-            const int prev_b = __shfl_up(b_row, 1);
-            const int pb = idx > 0 ? prev_b : -8; // (the valid samples are consecutive lanes)
-            const bool new_a = valid && use_lo && b_row - 1 > pb;
-            const bool new_b = valid && b_row > pb;
-            const unsigned long long mask_a = __ballot(new_a), mask_b = __ballot(new_b);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const int pos_a = __popcll(mask_a & below) + __popcll(mask_b & below);
-            const int pos_b = pos_a + (new_a ? 1 : 0);
-#ifdef RCL_EXP_NOROWS
-            const int nrows = 0 * (__popcll(mask_a) + __popcll(mask_b)); // experiment: set-up and epilogue alone
+#ifdef RCL_EXP_NORING
+            const bool ring = false;
 #else
-            const int nrows = __popcll(mask_a) + __popcll(mask_b);
+            const bool ring = S.c1 - c0 < RCL_RING_CELLS;
 #endif
-            const int ra = __builtin_amdgcn_ds_permute((new_a ? pos_a : 63) * 4, b_row);     // (row + 1) of b_row - 1
-            const int rb = __builtin_amdgcn_ds_permute((new_b ? pos_b : 63) * 4, b_row + 1);
-#ifdef RCL_EXP_ONEROW
-            const int v_rows = 0 * max(max(ra, rb) - 1, 0); // experiment: every row fetch hits the same cells
-#else
-            const int v_rows = max(max(ra, rb) - 1, 0);
-#endif
-            // the weight of list row `lane` in each bin row
-            float v_wy[7];
+            // tap j, wave-uniform: weight (low word) and byte offset of its cell inside a row -- of the map, or of
+            // the ring's image of the row, where cells are 256 bytes apart (high word)
+            const int tap_bytes = ring ? RCL_CH * 4 : cell_bytes;
+            uint64_t wx[28];
 #pragma unroll
-            for (int ph = 0; ph < 7; ++ph) v_wy[ph] = 0.0f;
-#pragma unroll
-            for (int sidx = 0; sidx < 14; ++sidx) {
-                const int sb = __builtin_amdgcn_readlane(b_row, 32 + sidx);
-                const float wl = rcl_readlane(s_wl, 32 + sidx), wh = rcl_readlane(s_wh, 32 + sidx);
-                const float w = (v_rows == sb ? wh : 0.0f) + (v_rows == sb - 1 ? wl : 0.0f);
-                v_wy[sidx >> 1] += lane < nrows ? w : 0.0f;
-            }
-            const int t = idx & 3;
-            const int v_cell = (t == 0 ? tx.idx[0] : t == 1 ? tx.idx[1] : t == 2 ? tx.idx[2] : tx.idx[3]) * cell_bytes;
-            const float v_xw = t == 0 ? tx.w[0] : t == 1 ? tx.w[1] : t == 2 ? tx.w[2] : tx.w[3];
+            for (int j = 0; j < 28; ++j)
+                wx[j] = ((uint64_t)(uint32_t)(__builtin_amdgcn_readlane(S.v_cell, j) * tap_bytes) << 32) |
+                        (uint32_t)__builtin_amdgcn_readlane(__float_as_uint(S.v_xw), j);
             const long long slice_bytes = (long long)H * W * cell_bytes;
             const char *base = blocked ? (const char *)feat + ((long long)b * cgroups + g) * slice_bytes
                                        : (const char *)feat + (long long)b * slice_bytes + g * (RCL_CH * 4);
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)base, 0, (int)(blocked ? slice_bytes : slice_bytes - g * (RCL_CH * 4)), 0x00020000);
-            if (x3)
-                rcl_item<3>(acc, rsrc, lane8, W * cell_bytes, v_cell, v_xw, v_rows, v_wy, nrows);
-            else
-                rcl_item<4>(acc, rsrc, lane8, W * cell_bytes, v_cell, v_xw, v_rows, v_wy, nrows);
+            if (ring) {
+                if (x3)
+                    rcl_item_ring<3>(acc, rsrc, lane, W * cell_bytes, cell_bytes, c0, wx, S.v_rows, S.v_wy, nrows, sw);
+                else
+                    rcl_item_ring<4>(acc, rsrc, lane, W * cell_bytes, cell_bytes, c0, wx, S.v_rows, S.v_wy, nrows, sw);
+            } else if (x3) {
+                rcl_item<3>(acc, rsrc, lane8, W * cell_bytes, wx, S.v_rows, S.v_wy, nrows);
+            } else {
+                rcl_item<4>(acc, rsrc, lane8, W * cell_bytes, wx, S.v_rows, S.v_wy, nrows);
+            }
         }
         // Through LDS, so that the run of RCL_CH x 49 floats leaves as 16-byte stores.
         const float4 *s4 = reinterpret_cast<const float4 *>(sw);
         float4 *o4 = reinterpret_cast<float4 *>(o);
-#if RCL_CPL == 2
-        // a lane holds out[lane][0..48] (.x) and out[lane + 64][0..48] (.y): 64 channels (12,544 bytes) at a time
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float *d = sw + lane * 49;
-#pragma unroll
-            for (int k = 0; k < 49; ++k) d[k] = h ? acc[k].y : acc[k].x;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 12; ++k) rcl_store(o4 + h * 784 + k * 64 + lane, s4[k * 64 + lane]);
-            if (lane < 16) rcl_store(o4 + h * 784 + 12 * 64 + lane, s4[12 * 64 + lane]);
-            __builtin_amdgcn_wave_barrier();
-        }
-#else
         // a lane holds out[lane][0..48]: 32 channels (6,272 bytes) at a time -- half the LDS per wave, which is what
         // lets sixteen and more waves share a CU
 #pragma unroll
@@ -512,7 +589,6 @@ roi_align_cl_kernel(ClLevels L, int C, int cgroups, int blocked, int chunks, int
             if (lane < 8) rcl_store(o4 + h * 392 + 6 * 64 + lane, s4[6 * 64 + lane]);
             __builtin_amdgcn_wave_barrier();
         }
-#endif
     }
 }
 
@@ -642,7 +718,7 @@ extern "C" int frcnn_roi_align_levels_cl_f32(const float *const *feats, const in
     const long long grid = sus * chunks * 8;
     FRCNN_REQUIRE(grid < (1ll << 31), "roi_align_levels_cl: grid too large");
     hipLaunchKernelGGL(roi_align_cl_kernel, dim3((unsigned)grid), dim3(RCL_THREADS), 0, st, L, C, cgroups,
-                       maps_channels_last ? 0 : 1, chunks, chunk_rois, padded, recs, B, out);
+                       maps_channels_last ? 0 : 1, chunks, chunk_rois, padded, (const ClRec *)recs, B, out);
     FRCNN_CHECK_LAUNCH("roi_align_cl");
     return FRCNN_OK;
 }
