@@ -196,7 +196,9 @@ __device__ __forceinline__ float rcl_readlane(float v, int lane)
 // (Computing these once per RoI in a launch of its own and loading them here -- 1,152 bytes per RoI, x taps by scalar
 // loads -- was built and measured: 0.986 against 0.944 ms at config 5; the table's load latency at the head of every
 // item costs more than the ~450 vector instructions it replaces.)
+#ifndef RCL_RING_CELLS
 #define RCL_RING_CELLS 16
+#endif
 struct ClSetup {
     int nrows;   // rows in the list (wave-uniform)
     bool x3;     // every bin's two x samples merge into three taps (wave-uniform)

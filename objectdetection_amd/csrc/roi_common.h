@@ -191,6 +191,18 @@ __device__ __forceinline__ AxisTaps axis_taps3(const AxisSample &s0, const AxisS
     return t;
 }
 
+// The pooled output is written once and not read again by these kernels.  roi_tile.hip defines RAP_STORE_NT: its
+// config-5 launch runs 0.856 -> 0.790 ms with `nt` stores; the plane kernel of roi.hip (headline shape) runs 1 %
+// slower with them and keeps plain stores.
+__device__ __forceinline__ void rap_out(float *p, float v)
+{
+#ifdef RAP_STORE_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 // All channel groups of one item: NY x NX taps, each ONE ds_read_b128 serving 4 channels.
 template <int NY, int NX, int GT>
 __device__ __forceinline__ void rap_item(const float4 *s_plane, int WS, int row_stride, int G, int nc,
@@ -219,10 +231,10 @@ __device__ __forceinline__ void rap_item(const float4 *s_plane, int WS, int row_
 #ifdef RT_EXP_NOSTORE
             if (lo.x + lo.y + hi.x + hi.y != 1234.5f) continue; // experiment: arithmetic without the store stream
 #endif
-            og[0] = lo.x;
-            og[49] = lo.y;
-            og[98] = hi.x;
-            og[147] = hi.y;
+            rap_out(og, lo.x);
+            rap_out(og + 49, lo.y);
+            rap_out(og + 98, hi.x);
+            rap_out(og + 147, hi.y);
         }
     } else {
         for (int g = 0; g < G; ++g) {
@@ -231,10 +243,10 @@ __device__ __forceinline__ void rap_item(const float4 *s_plane, int WS, int row_
 #pragma unroll
             for (int q = 0; q < NY * NX; ++q) pk_axpy4(lo, hi, wt[q], pl[off[q]]);
             float *og = o + (4 * g) * 49;
-            og[0] = lo.x;
-            if (4 * g + 1 < nc) og[49] = lo.y;
-            if (4 * g + 2 < nc) og[98] = hi.x;
-            if (4 * g + 3 < nc) og[147] = hi.y;
+            rap_out(og, lo.x);
+            if (4 * g + 1 < nc) rap_out(og + 49, lo.y);
+            if (4 * g + 2 < nc) rap_out(og + 98, hi.x);
+            if (4 * g + 3 < nc) rap_out(og + 147, hi.y);
         }
     }
 }

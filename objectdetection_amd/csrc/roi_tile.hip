@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#define RAP_STORE_NT 1 // see rap_out (roi_common.h)
 #include "roi_common.h"
 
 struct TileLevel {
