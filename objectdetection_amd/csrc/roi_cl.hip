@@ -29,7 +29,10 @@
 #endif
 #define RCL_CH 64 // channels per wave item: a lane is a channel
 #define RCL_WAVES (RCL_THREADS / 64)
-#define RCL_CHUNK_DEFAULT 2 // RoIs per workgroup (<= 64: a chunk's codes and boxes travel one per lane)
+// RoIs per workgroup (<= 64: a chunk's codes and boxes travel one per lane).  One: vector memory operations retire in
+// order, so the first row of a wave's next RoI would wait for the 14 stores of the one before it (config 5: 0.761 /
+// 0.772 / 0.794 / 0.820 / 0.996 ms at 1 / 2 / 3 / 4 / 8 RoIs per wave).
+#define RCL_CHUNK_DEFAULT 1
 #define RCL_MAX_UNITS 16
 #ifndef RCL_BAND_BYTES
 #define RCL_BAND_BYTES (1536 * 1024)
@@ -473,12 +476,15 @@ __device__ __forceinline__ void rcl_item_ring(float (&acc)[49], __amdgpu_buffer_
                                               int cell_bytes, int c0, const uint64_t (&wx)[28], int v_rows,
                                               const float (&v_wy)[7], int nrows, float *ring)
 {
-    // here the high word of wx[j] is 256 x tap j's cell: where the cell sits in a ring slot, c0's 256 bytes on
+    // here the high word of wx[j] is 256 x (tap j's cell - c0): where the cell sits in a ring slot
     int vaddr[7 * NX];
+    // (Computing them per row from the scalars instead -- one v_add per tap -- frees 24 registers, but the register
+    // path beside this one needs them anyway: 120 registers either way, and forced to 96 for five waves per SIMD
+    // the kernel spills and runs 1.00 against 0.77 ms.)
 #pragma unroll
     for (int p = 0; p < 7; ++p)
 #pragma unroll
-        for (int t = 0; t < NX; ++t) vaddr[p * NX + t] = ((int)(wx[p * 4 + t] >> 32) - c0 * 256) + lane * 4;
+        for (int t = 0; t < NX; ++t) vaddr[p * NX + t] = (int)(wx[p * 4 + t] >> 32) + lane * 4;
     const int vlane = (lane >> 4) * cell_bytes + (lane & 15) * 16;
     const int c0_bytes = c0 * cell_bytes;
     float *s0 = ring, *s1 = ring + RCL_SLOT_FLOATS;
@@ -551,11 +557,11 @@ roi_align_cl_kernel(ClLevels L, int C, int cgroups, int blocked, int chunks, int
 #endif
             // tap j, wave-uniform: weight (low word) and byte offset of its cell inside a row -- of the map, or of
             // the ring's image of the row, where cells are 256 bytes apart (high word)
-            const int tap_bytes = ring ? RCL_CH * 4 : cell_bytes;
+            const int tap_bytes = ring ? RCL_CH * 4 : cell_bytes, tap_c0 = ring ? c0 : 0;
             uint64_t wx[28];
 #pragma unroll
             for (int j = 0; j < 28; ++j)
-                wx[j] = ((uint64_t)(uint32_t)(__builtin_amdgcn_readlane(S.v_cell, j) * tap_bytes) << 32) |
+                wx[j] = ((uint64_t)(uint32_t)((__builtin_amdgcn_readlane(S.v_cell, j) - tap_c0) * tap_bytes) << 32) |
                         (uint32_t)__builtin_amdgcn_readlane(__float_as_uint(S.v_xw), j);
             const long long slice_bytes = (long long)H * W * cell_bytes;
             const char *base = blocked ? (const char *)feat + ((long long)b * cgroups + g) * slice_bytes
