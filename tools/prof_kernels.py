@@ -1,6 +1,6 @@
 """Small driver for rocprofv3 runs: exercises one stage of the hot path a few times.
 
-    python tools/prof_kernels.py roi|nms|topk|targets [reps]
+    python tools/prof_kernels.py roi|nms|topk|targets|roipool|bwd|bwd5 [reps]
 """
 import os
 import sys
@@ -36,9 +36,41 @@ def main():
         wh = torch.rand(B, 100, 2, generator=g) * 240 + 16
         xy = torch.rand(B, 100, 2, generator=g) * (torch.tensor([bench.IMG_W, bench.IMG_H]) - wh)
         gt = torch.cat([xy, xy + wh], 2).to(dev)
+    if what == "roipool":  # K7 at the headline shape (bench.roipool_microbench's boxes)
+        rng = np.random.default_rng(11)
+        n = B * bench.POST_NMS
+        cx, cy = rng.uniform(0, bench.IMG_W, n), rng.uniform(0, bench.IMG_H, n)
+        w, h = 16 * 2 ** rng.uniform(0, 5, n), 16 * 2 ** rng.uniform(0, 5, n)
+        pp = np.stack([(cx - w / 2).clip(0, bench.IMG_W), (cy - h / 2).clip(0, bench.IMG_H), (cx + w / 2).clip(0, bench.IMG_W),
+                       (cy + h / 2).clip(0, bench.IMG_H)], 1).astype(np.float32)
+        pool_props = torch.as_tensor(pp.reshape(B, bench.POST_NMS, 4)).to(dev)
+    if what == "bwd":  # RoIAlign backward at the headline shape, the step's own proposals
+        cfg = ((7, 7), 2, (1.0 / 16,), 4, 4)
+        total = int(n_keep.sum())
+        g_out = torch.randn((B * bench.POST_NMS, feat.shape[1], 7, 7), device=dev)
+        shapes = [tuple(feat.shape)]
+    if what == "bwd5":  # RoIAlign backward at BASELINE configs[4] (four FPN levels)
+        x = bench.config5_inputs(B, dev)
+        tv, ti = ops.topk_desc_nchw(x["cls"], 30000)
+        b5, _, _, c5 = ops.decode_clip_filter_nchw(x["anchors"], x["reg"], ti, tv, x["Himg"], x["Wimg"], 1e-3)
+        k5, nk5 = ops.nms_sorted(b5, c5, 0.7, 2000)
+        p5 = ops.gather_boxes(b5, k5, nk5)
+        from objectdetection_amd.ROIHead.roi_pooling import ROIPooling
+        feats5 = [f.requires_grad_(True) for f in x["feats"][::-1]]
+        pool5 = ROIPooling(['1', '2', '3', '4'], [7, 7], 2)
+        out5, _ = pool5.forward_padded({str(i + 1): f for i, f in enumerate(feats5)}, p5, nk5, [(x["Himg"], x["Wimg"])])
+        g5 = torch.randn_like(out5)
     torch.cuda.synchronize()
     for _ in range(reps):
-        if what == "targets":
+        if what == "roipool":
+            ops.roi_pool_batched(feat, pool_props, None, (7, 7), 1.0 / 16)
+        elif what == "bwd":
+            ops.roi_align_levels_backward(cfg, props, n_keep, g_out, shapes)
+        elif what == "bwd5":
+            for f in feats5:
+                f.grad = None
+            out5.backward(g5, retain_graph=True)
+        elif what == "targets":
             ops.iou_label_encode(anchors, gt, None, 0.3, 0.7)
         elif what == "roi":
             path.pool.forward_padded({'1': feat}, props, n_keep, [(bench.IMG_H, bench.IMG_W)])
