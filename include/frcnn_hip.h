@@ -263,8 +263,9 @@ int frcnn_roi_align_levels_f32(const float *const *feats, const int32_t *hw, con
 
 /* The same pooling with LANES = CHANNELS on channel-innermost maps (csrc/roi_cl.hip; same reference lines:
  * ROIHead/roi_pooling.py:44-53, ROIHead/roi_head.py:127-130, BackBone/fpn.py:91-96).  A wave takes (RoI, 64
- * channels), loads coalesced 256-byte pieces of cells straight from L2, keeps the 49 sums of a channel in registers
- * and contracts every cell row of a RoI's footprint once; no LDS staging, no RoI size limit.
+ * channels), keeps the 49 sums of a channel in registers and contracts every cell row of a RoI's footprint once: the
+ * row comes through a wave-private LDS ring (buffer_load_dwordx4 ... lds) when the RoI's x taps span <= 16 cells, as
+ * coalesced 256-byte loads into registers otherwise; no window of the map is staged, no RoI size limit.
  * maps_channels_last != 0: feats[l] is laid out (B, h_l, w_l, C) (torch.channels_last memory) and read in place;
  * maps_channels_last == 0: feats[l] is (B, C, h_l, w_l) and is first copied to that layout inside `workspace`.
  * Same outputs as frcnn_roi_align_levels_f32 (row order, zero rows, total_out), values equal up to the summation

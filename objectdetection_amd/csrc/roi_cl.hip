@@ -3,21 +3,23 @@
 // ROIHead/roi_head.py:127-130) on the FPN of BackBone/fpn.py:91-96.
 //
 // The plane / window / tile kernels (roi.hip, roi_tile.hip) stage NCHW cells in LDS and give a lane one BIN;
-// on planes beyond LDS the staging cannot overlap the items.  Here a lane is a CHANNEL and nothing is staged:
+// on planes beyond LDS the staging cannot overlap the items.  Here a lane is a CHANNEL and no window is staged:
 //   out[c, ph, pw] = sum_y Wy[ph, y] * sum_x Wx[pw, x] * F[y, x, c]      (RoIAlign's bilinear weights are separable)
-// On a map laid out (B, H, W, C) a wave takes (RoI, 64 channels): every load is one coalesced 256-byte piece of a
-// cell, every weight and every cell address is wave-uniform (scalar registers), the 49 sums of a channel live in
-// the lane's registers, and the RoI's 64 x 49 block leaves through a wave-private LDS transposition as one
-// contiguous 12.5 KB run of 16-byte stores.  Rows are walked once: the 14 row samples of a RoI ascend, so a
-// two-row window (the x-contracted rows T[lo], T[lo + 1]) slides down the footprint and each cell row is
-// contracted along x exactly once (7 x 3 or 7 x 4 loads) whatever the number of bins that use it.
-// No RoI size limit, no LDS bank conflicts, no per-item tap set-up beyond 14 + 14 samples computed by the lanes
-// of the wave in parallel.
+// On a map laid out (B, H, W, C) a wave takes (RoI, 64 channels): every weight and every cell address is wave-uniform
+// (scalar registers), the 49 sums of a channel live in the lane's registers, and the RoI's 64 x 49 block leaves through
+// a wave-private LDS transposition as one contiguous 12.5 KB run of 16-byte stores.  Rows are walked once: the 14 row
+// samples of a RoI ascend, so each cell row the samples touch is fetched and contracted along x exactly once (into 7
+// registers) whatever the number of bins that use it, and added to the bin rows in which it has weight.
+// A row arrives in one of two ways: when the x taps span at most 16 cells, as those 16 cells by four
+// `buffer_load_dwordx4 ... lds` into a wave-private two-slot LDS ring, from which the 21-28 taps are ds_read_b32 (lane =
+// channel: no bank conflicts; every cell fetched once although neighbouring bins share cells); otherwise as 21-28
+// coalesced 256-byte loads into registers (no RoI size limit).
 // Work order: a preparation launch sorts every image's RoIs by (level, band of rows) -- a band's 64-channel slice
-// is at most ~1.5 MB -- and the main launch hands consecutive workgroups of one XCD consecutive chunks of one
+// is at most ~1.5 MB -- and the main launch hands consecutive workgroups of one XCD consecutive RoIs of one
 // (image, channel group), so that the cells a band's RoIs share are served by that XCD's L2.
-// NCHW maps (what the reference's FPN produces) are first copied to the channel-innermost layout in the caller's
-// workspace (one pass, fused with the preparation launch); maps that already are channels-last are read in place.
+// NCHW maps (what the reference's FPN produces) are first copied to a channel-innermost layout blocked by 64 channels
+// in the caller's workspace (one pass); maps that already are channels-last are read in place.
+// Measurements, what bounds the kernel and what was tried and dropped: DESIGN.md section 4.
 #include <math.h>
 #include <stdlib.h>
 
