@@ -6,7 +6,7 @@
 //
 // torchvision scatters with one global float atomic per tap (16 per output element).  Here a workgroup owns
 // (image, channel chunk, RoI split) and keeps the chunk's GRADIENT PLANES in LDS, one wave per channel pair, and the
-// scatter needs no atomics: RoIAlign's weights are separable, so per RoI the update of a channel is Wy^T (G Wx), two
+// scatter needs no atomics: RoIAlign's weights are separable, so per RoI the update of a channel is Wx^T (G^T Wy), two
 // small matrix products that run on the fp32 MFMA (see roi_align_plane_backward_kernel); HBM sees grad_out once plus
 // one write of the planes, and with one workgroup per (image, chunk) the result is deterministic.  Planes too large
 // for four channels of them to fit LDS (FPN P3 / P2 at 800 x 1344) are walked window by window
@@ -56,9 +56,9 @@ __device__ __forceinline__ bool axis_range(float start, float bin, int n, int &c
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// grad_out of one RoI as the A operand of the column contraction (v_mfma_f32_16x16x4_f32: A[i][k] in lane i + 16 k):
-// row i = 4 g + v stands for (channel v / 2, bin row ph = g + 4 (v % 2)), k for bin column pw = k (lo) and k + 4 (hi);
-// rows and columns that do not exist (ph = 7, pw = 7) are zero.  Two dword loads per lane and RoI, each wave
+// grad_out of one RoI as the A operand of the ROW contraction (v_mfma_f32_16x16x4_f32: A[i][k] in lane i + 16 k):
+// row i = 4 g + v stands for (channel v / 2, bin column pw = g + 4 (v % 2)), k for bin row ph = k (lo) and k + 4 (hi);
+// rows and columns that do not exist (pw = 7, ph = 7) are zero.  Two dword loads per lane and RoI, each wave
 // instruction a gather inside two 196-byte runs.
 struct RabG {
     float lo, hi;
@@ -72,18 +72,22 @@ struct RabLane { // per-lane constants of the gather
 __device__ __forceinline__ RabLane rab_lane(int lane, int ch1_off)
 {
     const int i = lane & 15, k = lane >> 4;
-    const int v = i & 3, ph = (i >> 2) + 4 * (v & 1);
+    const int v = i & 3, pw = (i >> 2) + 4 * (v & 1);
     RabLane L;
-    L.ok_lo = ph < 7;
-    L.ok_hi = ph < 7 && k < 3;
-    const int row = (v >> 1) * ch1_off + (L.ok_lo ? ph : 0) * 7;
-    L.off_lo = row + k;
-    L.off_hi = row + (L.ok_hi ? k + 4 : k);
+    L.ok_lo = pw < 7;
+    L.ok_hi = pw < 7 && k < 3;
+    const int col = (v >> 1) * ch1_off + (L.ok_lo ? pw : 0);
+    L.off_lo = col + k * 7;
+    L.off_hi = col + (L.ok_hi ? k + 4 : k) * 7;
     return L;
 }
 
 __device__ __forceinline__ void rab_load(RabG &g, const float *__restrict__ gb, int j, int C, const RabLane &L)
 {
+#ifdef RAB_EXP_NOLOAD
+    g.lo = g.hi = 1.0f; // experiment: the walk without grad_out
+    return;
+#endif
     const float *gp = gb + (long long)j * C * 49;
     // Issued by hand and waited for by hand (rab_wait): the compiler's own counter bookkeeping gives up on a rotating
     // set of loads in a loop with exits and waits for ALL of them before every second RoI.
@@ -108,45 +112,73 @@ __device__ __forceinline__ void rab_drain(RabG (&G)[RAB_DEPTH])
                    "+v"(G[3].lo), "+v"(G[3].hi), "+v"(G[4].lo), "+v"(G[4].hi), "+v"(G[5].lo), "+v"(G[5].hi));
 }
 
-// One RoI, two channels, lane = (q = lane / 16, li = lane % 16).  Per block of 16 columns: B = Wx (lane (q, li) reads
-// Wx[q][xb + li] and Wx[q + 4][xb + li] from the column table; entry 7 is zero), two MFMAs leave
-// T[ph][x] = sum_pw G[ph][pw] Wx[pw][x] as D rows, i.e. lane (q, li) holds T[q][x], T[q + 4][x] of channel 0 and of
-// channel 1 -- which is the B operand layout of the row contraction (B[k][j] in lane j + 16 k).  Per block of 16 rows:
-// A = Wy^T (lane (q, li) reads Wy[q][rb + li], Wy[q + 4][rb + li] from the row table), two MFMAs per channel leave
-// D[row][x] = sum_ph Wy[ph][row] T[ph][x] as four rows rb + 4 q + v per lane, added to the cells; rows / columns
-// outside the footprint go to a dummy cell.
-__device__ __forceinline__ void rab_scatter(const RabG &g, const RabLane &L, const float *s_tab, int e_off, int e_ymin,
-                                            int e_ny, int e_xmin, int e_nx, int W, int q, int li, char *lds,
-                                            const unsigned (&cell_v)[4], unsigned dummy)
+// Where the planes of a workgroup live in LDS: [first channels of the nw waves: nw planes][dummy: 16 B per lane]
+// [second channels: nw planes][dummy], a plane = rows of SX floats (SX a multiple of 4, so that the four cells a lane
+// owns in a block are one 16-byte access).  Lanes li = 0..7 of an access are 8 consecutive rows: they fall into 8
+// different 16-byte bank groups either because SX / 4 is odd or, when SX is a multiple of 32 (`swz`), because the
+// 16-byte group index of a cell is XORed with (row & 7).
+struct RabPlanes {
+    int SX;        // floats per plane row
+    int swz;       // 1: byte offset inside a row ^= (row & 7) << 4
+    unsigned pb;   // bytes per plane
+    unsigned ch1;  // bytes from a wave's first plane to its second (= from the first dummy area to the second)
+    int zero_ent;  // table entry whose 8 floats are zero
+};
+
+__device__ __forceinline__ unsigned rab_cell(const RabPlanes &PL, int y, int x)
 {
-    // cell_v[v] = byte offset in LDS of this lane's cell of row 4 q + v, column li of the wave's planes; the block's
-    // origin is a scalar on top.  Rows the lane owns in a block: v < nrow.
+    return (unsigned)(y * PL.SX * 4) + ((unsigned)(x * 4) ^ (PL.swz ? (unsigned)(y & 7) << 4 : 0u));
+}
+
+// One RoI, two channels, lane = (q = lane / 16, li = lane % 16).  Per block of 16 ROWS: B = Wy (lane (q, li) reads
+// Wy[q][yb + li] and Wy[q + 4][yb + li] from the row table; entry 7 is zero), two MFMAs leave
+// T[pw][y] = sum_ph G[ph][pw] Wy[ph][y] as D rows, i.e. lane (q, li) holds T[q][y], T[q + 4][y] of channel 0 and of
+// channel 1 -- which is the B operand layout of the column contraction (B[k][j] in lane j + 16 k).  Per block of 16
+// COLUMNS: A = Wx^T (lane (q, li) reads Wx[q][x], Wx[q + 4][x] of column x = xb + li from the column table, the zero
+// entry when x is outside the footprint), two MFMAs per channel leave D[x][y] = sum_pw Wx[pw][x] T[pw][y] as the four
+// columns xb + 4 q + v of row yb + li per lane: four neighbouring cells of one plane row = ONE 16-byte LDS access per
+// channel to read them, one to write them back (blocks start on a multiple of 4 columns).  Lanes whose row or column
+// group lies outside the footprint go to a dummy; columns outside it inside a group add the zero the zero entry gives.
+__device__ __forceinline__ void rab_scatter(const RabG &g, const RabLane &L, const float *s_tab, const RabPlanes &PL,
+                                            int e_off, int e_ymin, int e_ny, int e_xmin, int e_nx, int q, int li,
+                                            char *lds, unsigned wave_base, unsigned dummy)
+{
+#ifdef RAB_EXP_NOSCATTER
+    asm volatile("" ::"v"(g.lo), "v"(g.hi)); // experiment: the walk's skeleton (loads, waits, RoI bookkeeping) alone
+    return;
+#endif
     const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
     const float glo = L.ok_lo ? g.lo : 0.0f, ghi = L.ok_hi ? g.hi : 0.0f;
-    for (int xb = 0; xb < e_nx; xb += 16) {
-        const int xc = xb + li;
-        const float *wp = s_tab + (e_off + e_ny + min(xc, e_nx - 1)) * 8 + q;
+    const int shift = e_xmin & 3, x0 = e_xmin - shift, nxe = e_nx + shift; // blocks start at column x0 of the plane
+    for (int yb = 0; yb < e_ny; yb += 16) {
+        const int yr = yb + li;
+        const float *wp = s_tab + (e_off + min(yr, e_ny - 1)) * 8 + q;
         f32x4 t = __builtin_amdgcn_mfma_f32_16x16x4f32(glo, wp[0], z, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x4f32(ghi, wp[4], t, 0, 0, 0);
-        const int rows_here = xc < e_nx ? e_ny - 4 * q : 0;
-        for (int rb = 0; rb < e_ny; rb += 16) {
-            const float *ap = s_tab + (e_off + min(rb + li, e_ny - 1)) * 8 + q;
+        const int y = e_ymin + yr;
+        const unsigned rowb = wave_base + (unsigned)(y * PL.SX * 4);
+        const unsigned sw = PL.swz ? (unsigned)(y & 7) << 4 : 0u;
+        const int groups_here = yr < e_ny ? nxe - 4 * q : 0; // > xb: this lane's four columns take part
+        for (int xb = 0; xb < nxe; xb += 16) {
+            // (reading the column entry of block xb + 16 here, one block ahead of its use, was measured: 3.38 against
+            // 3.25 ms -- the extra read behind the last block costs more than the latency the others hide)
+            const int xi = xb + li - shift;
+            const float *ap = s_tab + ((unsigned)xi < (unsigned)e_nx ? e_off + e_ny + xi : PL.zero_ent) * 8 + q;
             const float alo = ap[0], ahi = ap[4];
             f32x4 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t.x, z, 0, 0, 0);
             f32x4 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(alo, t.z, z, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t.y, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ahi, t.w, acc1, 0, 0, 0);
-            const int nrow = rows_here - rb;
-            const unsigned origin = (unsigned)(((e_ymin + rb) * W + e_xmin + xb) * 8);
-            f32x2 *p0 = (f32x2 *)(lds + (0 < nrow ? cell_v[0] + origin : dummy));
-            f32x2 *p1 = (f32x2 *)(lds + (1 < nrow ? cell_v[1] + origin : dummy));
-            f32x2 *p2 = (f32x2 *)(lds + (2 < nrow ? cell_v[2] + origin : dummy));
-            f32x2 *p3 = (f32x2 *)(lds + (3 < nrow ? cell_v[3] + origin : dummy));
-            const f32x2 o0 = *p0, o1 = *p1, o2 = *p2, o3 = *p3;
-            *p0 = (f32x2){o0.x + acc0.x, o0.y + acc1.x};
-            *p1 = (f32x2){o1.x + acc0.y, o1.y + acc1.y};
-            *p2 = (f32x2){o2.x + acc0.z, o2.y + acc1.z};
-            *p3 = (f32x2){o3.x + acc0.w, o3.y + acc1.w};
+#ifdef RAB_EXP_NORMW
+            asm volatile("" ::"v"(acc0), "v"(acc1)); // experiment: both contractions without the LDS read-modify-write
+            continue;
+#endif
+            const unsigned col = (unsigned)((x0 + xb + 4 * q) * 4);
+            const unsigned a0 = xb < groups_here ? rowb + (col ^ sw) : dummy;
+            f32x4 *p0 = (f32x4 *)(lds + a0), *p1 = (f32x4 *)(lds + a0 + PL.ch1);
+            const f32x4 o0 = *p0, o1 = *p1;
+            *p0 = o0 + acc0;
+            *p1 = o1 + acc1;
         }
     }
 }
@@ -154,11 +186,12 @@ __device__ __forceinline__ void rab_scatter(const RabG &g, const RabLane &L, con
 // 64 candidate RoIs, one per lane (live: to be walked; rec: its record; jidx: its row among the image's RoIs; every
 // wave of the workgroup holds the same values): footprints and table sizes, then batch after batch -- as many RoIs as
 // the table space holds -- the tables are built by all waves and every wave walks the batch for its two channels.
-// The planes are PW cells wide and start at cell (oy, ox) of the H x W map.  Contains workgroup barriers.
-__device__ __forceinline__ void rab_walk64(bool live, const float4 rec, int jidx, int n_cand, int H, int W, int PW, int oy,
+// The planes (layout PL) start at cell (oy, ox) of the H x W map.  Contains workgroup barriers.
+__device__ __forceinline__ void rab_walk64(bool live, const float4 rec, int jidx, int n_cand, int H, int W,
+                                           const RabPlanes &PL, int oy,
                                            int ox, float *s_tab, int cap, int nw, int wave, int lane, bool has0,
                                            const float *__restrict__ gb, int C, const RabLane &GL, char *lds,
-                                           const unsigned (&cell_v)[4], unsigned dummy)
+                                           unsigned wave_base, unsigned dummy)
 {
     const int q = lane >> 4, li = lane & 15;
     int ymin = 0, ymax = 0, xmin = 0, xmax = 0;
@@ -181,6 +214,9 @@ __device__ __forceinline__ void rab_walk64(bool live, const float4 rec, int jidx
         m = min(m, n_cand - done);
         const int my_off = pre - ent - base; // first entry of this lane's RoI
         __syncthreads(); // the previous batch's tables have been used
+#ifdef RAB_EXP_NOTABLES
+        if (false) // experiment: the walk on whatever the table space holds
+#endif
         for (int g = wave * 4; g < m; g += nw * 4) {
             // ---- tables of RoIs done + g .. + 3: 16 lanes per RoI, lane = (axis, bin) for the scatter
             const int src = min(done + g + (lane >> 4), 63);
@@ -242,7 +278,7 @@ __device__ __forceinline__ void rab_walk64(bool live, const float4 rec, int jidx
                         const int e_ymin = __builtin_amdgcn_readlane(ymin, e), e_ny = __builtin_amdgcn_readlane(ny, e);
                         const int e_xmin = __builtin_amdgcn_readlane(xmin, e), e_nx = __builtin_amdgcn_readlane(nx, e);
                         rab_wait(G[d]);
-                        rab_scatter(G[d], GL, s_tab, e_off, e_ymin - oy, e_ny, e_xmin - ox, e_nx, PW, q, li, lds, cell_v, dummy);
+                        rab_scatter(G[d], GL, s_tab, PL, e_off, e_ymin - oy, e_ny, e_xmin - ox, e_nx, q, li, lds, wave_base, dummy);
                         E[d] = next();
                         rab_load(G[d], gb, __builtin_amdgcn_readlane(jidx, E[d] >= 0 ? E[d] : e_first), C, GL);
                     }
@@ -256,16 +292,16 @@ __device__ __forceinline__ void rab_walk64(bool live, const float4 rec, int jidx
 }
 
 // Workgroup = (image, chunk of 2 nw channels, RoI split), nw waves: WAVE w OWNS CHANNELS c0 + 2w, c0 + 2w + 1 and
-// their gradient planes in LDS (interleaved: one float2 per cell), so no two waves ever add into the same plane, and
-// inside a wave the lanes are distinct CELLS of the RoI's footprint: the scatter needs no atomics, it is ds_read_b64,
-// add, ds_write_b64.  (LDS float atomics are what the first version used: ds_add_f32 costs ~130 cycles per wave
+// their gradient planes in LDS (two planes, layout RabPlanes), so no two waves ever add into the same plane, and
+// inside a wave the lanes are distinct groups of four neighbouring CELLS of the RoI's footprint: the scatter needs no
+// atomics, it is ds_read_b128, add, ds_write_b128 per channel.  (LDS float atomics are what the first version used: ds_add_f32 costs ~130 cycles per wave
 // instruction on gfx950 whether or not lanes collide -- 68 ms at the headline shape, against 3.4 ms for this form.)
 //
-// RoIAlign's weights are separable: grad_feat[y][x] += sum_ph Wy[ph][y] * (sum_pw G[ph][pw] * Wx[pw][x]), Wy / Wx =
+// RoIAlign's weights are separable: grad_feat[y][x] += sum_pw Wx[pw][x] * (sum_ph G[ph][pw] * Wy[ph][y]), Wy / Wx =
 // the weight that the two samples of bin row ph / column pw put on cell row y / column x.  Per RoI the workgroup
 // builds both as TABLES in LDS once (an entry = the 7 weights of one cell row or column; rows carry the 1/4 of the
 // 2 x 2 average), for as many RoIs at a time as the table space holds; every wave then walks those RoIs for its two
-// channels (rab_scatter: both contractions as 16 x 16 x 4 fp32 MFMAs, the column one for the two channels at once;
+// channels (rab_scatter: both contractions as 16 x 16 x 4 fp32 MFMAs, the row one for the two channels at once;
 // grad_out of the next RAB_DEPTH RoIs in flight, because a wave's RoIs are a serial chain of dependent loads
 // otherwise).
 // HBM sees grad_out once plus one write of the planes; one workgroup per (image, chunk) -> deterministic sums.
@@ -274,14 +310,20 @@ __global__ void __launch_bounds__(512)
 roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H, int W,
                                 const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
                                 float scale, int level, int n_levels, int k_min, int k_max, int chunks,
-                                int splits, int B, int tab_off, int cap, float *__restrict__ grad_feat)
+                                int splits, int B, int SX, int swz, int cap, float *__restrict__ grad_feat)
 {
-    extern __shared__ __align__(16) float s_dyn[]; // [nw][H * W] float2 planes, then the tables: cap entries of 8 floats
+    // planes and dummies (RabPlanes), then the tables: cap entries of 8 floats and the zero entry
+    extern __shared__ __align__(16) float s_dyn[];
     __shared__ int s_off, s_cnt;
-    __shared__ f32x2 s_dummy[64]; // per lane: where the masked lanes of a block add (same-address writes would serialise)
-    f32x2 *const s_pl = (f32x2 *)s_dyn;
-    float *const s_tab = s_dyn + tab_off;
     const int nw = blockDim.x >> 6;
+    RabPlanes PL;
+    PL.SX = SX;
+    PL.swz = swz;
+    PL.pb = (unsigned)(H * SX * 4);
+    PL.ch1 = (unsigned)nw * PL.pb + 1024u;
+    PL.zero_ent = cap;
+    const unsigned planes_bytes = 2u * PL.ch1;
+    float *const s_tab = s_dyn + planes_bytes / 4;
     const int chunk = blockIdx.x % chunks;
     const int grp = blockIdx.x / chunks;
     const int split = grp % splits;
@@ -301,7 +343,9 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
         }
         s_off = off;
     }
-    for (int t = threadIdx.x; t < nw * HW; t += blockDim.x) s_pl[t] = (f32x2){0.0f, 0.0f};
+    for (unsigned t = threadIdx.x; t < planes_bytes / 16; t += blockDim.x)
+        reinterpret_cast<float4 *>(s_dyn)[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (threadIdx.x < 8) s_tab[cap * 8 + threadIdx.x] = 0.0f;
     __syncthreads();
     const int cnt = s_cnt;
     const int per = (cnt + splits - 1) / splits;
@@ -310,13 +354,10 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
     const int ch0 = c0 + 2 * wave;
     const bool has0 = ch0 < C, has1 = ch0 + 1 < C;
     const float *gb = grad_out + ((long long)s_off * C + min(ch0, C - 1)) * 49;
-    const int q = lane >> 4, li = lane & 15;
     const RabLane GL = rab_lane(lane, has1 ? 49 : 0);
     char *const lds = (char *)s_dyn;
-    const unsigned dummy = (unsigned)((char *)(s_dummy + lane) - lds);
-    unsigned cell_v[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) cell_v[v] = (unsigned)((wave * HW + (4 * q + v) * W + li) * 8);
+    const unsigned dummy = (unsigned)nw * PL.pb + (unsigned)lane * 16u; // masked lanes add here (each its own 16 bytes)
+    const unsigned wave_base = (unsigned)wave * PL.pb;
     for (int jw = split * per; jw < j_end; jw += 64) {
         // ---- lane = candidate RoI jw + lane: footprint and table size (every wave computes the same values)
         bool live = jw + lane < j_end;
@@ -326,19 +367,23 @@ roi_align_plane_backward_kernel(const float *__restrict__ grad_out, int C, int H
             if (n_levels > 1 && map_level(box, k_min, k_max) != level) live = false;
             rec = rab_record(box, scale);
         }
-        rab_walk64(live, rec, jw + lane, min(64, j_end - jw), H, W, W, 0, 0, s_tab, cap, nw, wave, lane, has0, gb, C, GL, lds,
-                   cell_v, dummy);
+        rab_walk64(live, rec, jw + lane, min(64, j_end - jw), H, W, PL, 0, 0, s_tab, cap, nw, wave, lane, has0, gb, C, GL,
+                   lds, wave_base, dummy);
     }
     __syncthreads();
+    // ---- the planes leave row by row: a wave takes (channel, row) pairs, lanes = cells of the row
     float *out = grad_feat + ((long long)b * C + c0) * HW;
-    const float *s_f = (const float *)s_pl;
-    for (int t = threadIdx.x; t < nc * HW; t += blockDim.x) {
-        const int c = t / HW, cellidx = t - c * HW;
-        const float v = s_f[((c >> 1) * HW + cellidx) * 2 + (c & 1)];
-        if (splits == 1)
-            out[t] = v;
-        else if (v != 0.0f)
-            unsafeAtomicAdd(out + t, v);
+    for (int r = wave; r < nc * H; r += nw) {
+        const int c = r / H, y = r - c * H;
+        const char *pl = lds + ((c & 1) ? PL.ch1 : 0u) + (unsigned)(c >> 1) * PL.pb;
+        float *o = out + (long long)c * HW + (long long)y * W;
+        for (int x = lane; x < W; x += 64) {
+            const float v = *(const float *)(pl + rab_cell(PL, y, x));
+            if (splits == 1)
+                o[x] = v;
+            else if (v != 0.0f)
+                unsafeAtomicAdd(o + x, v);
+        }
     }
 }
 
@@ -357,15 +402,23 @@ __global__ void __launch_bounds__(RABW_THREADS)
 roi_align_window_backward_kernel(const float *__restrict__ grad_out, int C, int H, int W,
                                  const float4 *__restrict__ props, const int32_t *__restrict__ count, int P,
                                  float scale, int level, int n_levels, int k_min, int k_max, int nwy, int nwx,
-                                 int csplit, int B, int tab_off, int cap, float *__restrict__ grad_feat)
+                                 int csplit, int B, int cap, float *__restrict__ grad_feat)
 {
-    extern __shared__ __align__(16) float s_dyn[]; // [RABW_PAIRS][64 * 64] float2 windows, then the tables
+    // windows of RAW_WIN x RAW_WIN cells as planes (RabPlanes, rows of RAW_WIN floats, swizzled) and dummies, then the
+    // tables and the zero entry
+    extern __shared__ __align__(16) float s_dyn[];
     __shared__ int s_list[RABW_LIST];
     __shared__ int s_wave_sums[RABW_PAIRS];
     __shared__ int s_off, s_cnt;
-    __shared__ f32x2 s_dummy[64];
-    f32x2 *const s_pl = (f32x2 *)s_dyn;
-    float *const s_tab = s_dyn + tab_off;
+    static_assert(RAW_WIN % 32 == 0, "swizzled rows are whole 32-float blocks");
+    RabPlanes PL;
+    PL.SX = RAW_WIN;
+    PL.swz = 1;
+    PL.pb = RAW_WIN * RAW_WIN * 4u;
+    PL.ch1 = RABW_PAIRS * PL.pb + 1024u;
+    PL.zero_ent = cap;
+    const unsigned planes_bytes = 2u * PL.ch1;
+    float *const s_tab = s_dyn + planes_bytes / 4;
     const int cs = blockIdx.x % csplit;
     const int grp = blockIdx.x / csplit;
     const int wid = grp % (nwy * nwx);
@@ -385,15 +438,13 @@ roi_align_window_backward_kernel(const float *__restrict__ grad_out, int C, int 
         }
         s_off = off;
     }
+    if (threadIdx.x < 8) s_tab[cap * 8 + threadIdx.x] = 0.0f;
     __syncthreads();
     const int cnt = s_cnt;
     const float4 *pb = props + (long long)b * P;
     char *const lds = (char *)s_dyn;
-    const unsigned dummy = (unsigned)((char *)(s_dummy + lane) - lds);
-    const int q = lane >> 4, li = lane & 15;
-    unsigned cell_v[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) cell_v[v] = (unsigned)((wave * RAW_WIN * RAW_WIN + (4 * q + v) * RAW_WIN + li) * 8);
+    const unsigned dummy = RABW_PAIRS * PL.pb + (unsigned)lane * 16u;
+    const unsigned wave_base = (unsigned)wave * PL.pb;
     const int chunks = (C + 2 * RABW_PAIRS - 1) / (2 * RABW_PAIRS);
     for (int seg = 0; seg < cnt; seg += RABW_LIST) {
         // ---- the window's RoIs among seg .. seg + RABW_LIST - 1, in index order
@@ -420,22 +471,22 @@ roi_align_window_backward_kernel(const float *__restrict__ grad_out, int C, int 
             const bool has0 = ch0 < C, has1 = ch0 + 1 < C;
             const float *gb = grad_out + ((long long)s_off * C + min(ch0, C - 1)) * 49;
             const RabLane GL = rab_lane(lane, has1 ? 49 : 0);
-            for (int t = threadIdx.x; t < RABW_PAIRS * RAW_WIN * RAW_WIN; t += RABW_THREADS) s_pl[t] = (f32x2){0.0f, 0.0f};
+            for (unsigned t = threadIdx.x; t < planes_bytes / 16; t += RABW_THREADS)
+                reinterpret_cast<float4 *>(s_dyn)[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             __syncthreads();
             for (int lw = 0; lw < n_list; lw += 64) {
                 const bool live = lw + lane < n_list;
                 const int j = live ? s_list[lw + lane] : 0;
                 const float4 rec = live ? roi_record(pb[j], scale) : make_float4(0.0f, 0.0f, 1.0f, 1.0f);
-                rab_walk64(live, rec, j, min(64, n_list - lw), H, W, RAW_WIN, wy0, wx0, s_tab, cap, RABW_PAIRS, wave, lane,
-                           has0, gb, C, GL, lds, cell_v, dummy);
+                rab_walk64(live, rec, j, min(64, n_list - lw), H, W, PL, wy0, wx0, s_tab, cap, RABW_PAIRS, wave, lane,
+                           has0, gb, C, GL, lds, wave_base, dummy);
             }
             __syncthreads();
             // ---- add the windows to the map: rows of ww cells, coalesced
-            const float *s_f = (const float *)s_pl;
             for (int t = threadIdx.x; t < nc * wh * RAW_WIN; t += RABW_THREADS) {
                 const int c = t / (wh * RAW_WIN), rem = t - c * (wh * RAW_WIN);
                 const int y = rem / RAW_WIN, x = rem - y * RAW_WIN;
-                const float v = s_f[((c >> 1) * RAW_WIN * RAW_WIN + y * RAW_WIN + x) * 2 + (c & 1)];
+                const float v = *(const float *)(lds + ((c & 1) ? PL.ch1 : 0u) + (unsigned)(c >> 1) * PL.pb + rab_cell(PL, y, x));
                 if (x < ww && v != 0.0f)
                     unsafeAtomicAdd(grad_feat + ((long long)b * C + c0 + c) * HW + (long long)(wy0 + y) * W + wx0 + x, v);
             }
@@ -524,11 +575,18 @@ extern "C" int frcnn_roi_align_batched_backward_f32(const float *grad_out, int B
         return FRCNN_OK;
     }
     FRCNN_REQUIRE(grad_out && props, "roi_align_backward: null pointer");
-    // planes in LDS, one wave per channel pair: worth it from two waves (four channels) per workgroup on
-    const long long pair_bytes = (long long)H * W * 8;
-    const long long tab_min = (long long)(H + W) * 32 > 8192 ? (long long)(H + W) * 32 : 8192;
+    // planes in LDS, one wave per channel pair: worth it from two waves (four channels) per workgroup on.
+    // Plane rows (RabPlanes): W rounded up to 4 floats with an odd number of 16-byte groups, or to a multiple of 32
+    // with the groups swizzled by the row -- whichever is shorter.
+    int sx_odd = (W + 3) / 4 * 4;
+    if ((sx_odd / 4) % 2 == 0) sx_odd += 4;
+    const int sx_swz = (W + 31) / 32 * 32;
+    const int swz = sx_swz < sx_odd ? 1 : 0;
+    const int SX = swz ? sx_swz : sx_odd;
+    const long long pair_bytes = (long long)H * SX * 8;
+    const long long tab_min = ((long long)(H + W) * 32 > 8192 ? (long long)(H + W) * 32 : 8192) + 32; // + the zero entry
     int nw = 8;
-    while (nw >= 2 && nw * pair_bytes + 16 + tab_min > RAB_LDS_BUDGET) --nw;
+    while (nw >= 2 && nw * pair_bytes + 2048 + tab_min > RAB_LDS_BUDGET) --nw;
     if (pooled_h == 7 && pooled_w == 7 && sampling_ratio == 2 && nw >= 2 && (long long)P * 49 < (1ll << 30)) {
         if (2 * nw > C) nw = (C + 1) / 2;
         const int CC = 2 * nw;
@@ -543,18 +601,18 @@ extern "C" int frcnn_roi_align_batched_backward_f32(const float *grad_out, int B
             hipError_t e = hipMemsetAsync(grad_feat, 0, plane_elems * sizeof(float), st);
             FRCNN_REQUIRE(e == hipSuccess, "roi_align_backward: memset failed: %s", hipGetErrorString(e));
         }
-        const int tab_off = (int)(((long long)nw * H * W * 2 + 3) / 4 * 4); // floats; the tables start 16-byte aligned
-        long long cap = (RAB_LDS_BUDGET - (long long)tab_off * 4) / 32;
+        const long long planes_bytes = nw * pair_bytes + 2048; // + the two dummy areas
+        long long cap = (RAB_LDS_BUDGET - planes_bytes - 32) / 32;
         if (cap > RAB_TAB_MAX_ENTRIES) cap = RAB_TAB_MAX_ENTRIES;
         FRCNN_REQUIRE(cap >= H + W, "roi_align_backward: internal: table space %lld < %d entries", cap, H + W);
-        const size_t lds = (size_t)tab_off * 4 + (size_t)cap * 32;
+        const size_t lds = (size_t)planes_bytes + (size_t)(cap + 1) * 32;
         static size_t granted[FRCNN_MAX_DEVICES];
         hipError_t e = frcnn_reserve_dynamic_lds((const void *)roi_align_plane_backward_kernel, lds, granted);
         FRCNN_REQUIRE(e == hipSuccess, "roi_align_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
         FRCNN_REQUIRE((long long)B * chunks * splits < (1ll << 31), "roi_align_backward: grid too large");
         hipLaunchKernelGGL(roi_align_plane_backward_kernel, dim3((unsigned)(B * chunks * splits)), dim3(64 * nw),
                            lds, st, grad_out, C, H, W, (const float4 *)props, count, P, spatial_scale, level,
-                           n_levels, k_min, k_max, chunks, splits, B, tab_off, (int)cap, grad_feat);
+                           n_levels, k_min, k_max, chunks, splits, B, SX, swz, (int)cap, grad_feat);
         FRCNN_CHECK_LAUNCH("roi_align_plane_backward");
         return FRCNN_OK;
     }
@@ -572,18 +630,18 @@ extern "C" int frcnn_roi_align_batched_backward_f32(const float *grad_out, int B
             const int chunks = (C + 2 * RABW_PAIRS - 1) / (2 * RABW_PAIRS);
             int csplit = (int)((1024 + (long long)nwy * nwx * B - 1) / ((long long)nwy * nwx * B));
             csplit = csplit < 1 ? 1 : (csplit > chunks ? chunks : csplit);
-            const int tab_off = RABW_PAIRS * RAW_WIN * RAW_WIN * 2; // floats
+            const long long planes_bytes = 2ll * (RABW_PAIRS * RAW_WIN * RAW_WIN * 4 + 1024); // windows + dummy areas
             // beside the windows: the RoI list and the dummies (static), and tables for at least one RoI of a window
-            long long cap = (RAB_LDS_BUDGET - (long long)tab_off * 4 - RABW_LIST * 4 - 64) / 32;
+            long long cap = (RAB_LDS_BUDGET - planes_bytes - RABW_LIST * 4 - 64 - 32) / 32;
             if (cap > RAB_TAB_MAX_ENTRIES) cap = RAB_TAB_MAX_ENTRIES;
             FRCNN_REQUIRE(cap >= 2 * RAW_WIN, "roi_align_backward: internal: table space %lld entries", cap);
-            const size_t lds = (size_t)tab_off * 4 + (size_t)cap * 32;
+            const size_t lds = (size_t)planes_bytes + (size_t)(cap + 1) * 32;
             static size_t grantedw[FRCNN_MAX_DEVICES];
             e = frcnn_reserve_dynamic_lds((const void *)roi_align_window_backward_kernel, lds, grantedw);
             FRCNN_REQUIRE(e == hipSuccess, "roi_align_backward: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
             hipLaunchKernelGGL(roi_align_window_backward_kernel, dim3((unsigned)(nwy * nwx * B * csplit)),
                                dim3(RABW_THREADS), lds, st, grad_out, C, H, W, (const float4 *)props, count, P,
-                               spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, csplit, B, tab_off, (int)cap,
+                               spatial_scale, level, n_levels, k_min, k_max, nwy, nwx, csplit, B, (int)cap,
                                grad_feat);
             FRCNN_CHECK_LAUNCH("roi_align_window_backward");
         }
