@@ -482,7 +482,10 @@ __device__ __forceinline__ void rcl_item_ring(float (&acc)[49], __amdgpu_buffer_
     int vaddr[7 * NX];
     // (Computing them per row from the scalars instead -- one v_add per tap -- frees 24 registers, but the register
     // path beside this one needs them anyway: 120 registers either way, and forced to 96 for five waves per SIMD
-    // the kernel spills and runs 1.00 against 0.77 ms.)
+    // the kernel spills and runs 1.00 against 0.77 ms.  With the register path compiled out as well (every RoI through
+    // the ring: wrong for the 31 % of config 5's RoIs that are wider than it, timing only), taps read in rounds of seven
+    // and nothing spilled inside the row loop, five waves per SIMD run 0.833 ms against 0.746 for four: more waves
+    // are not what this kernel lacks, and the ring for every RoI would be worth 2.4 %.)
 #pragma unroll
     for (int p = 0; p < 7; ++p)
 #pragma unroll
