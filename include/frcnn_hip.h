@@ -285,8 +285,11 @@ int frcnn_roi_align_levels_cl_f32(const float *const *feats, const int32_t *hw, 
  * RoI losses train the backbone through the pooling).  Same arguments as the forward pass of one level;
  * grad_out: (>= sum(count), C, pooled_h, pooled_w) in the forward's row order; grad_feat: (B, C, H, W), written
  * in full (zeros where no RoI of this level reaches).  Every sample sends grad * w / (sampling_ratio^2) to its
- * four taps (torchvision roi_align_backward); boxes get no gradient.  The sum order over RoIs is not fixed
- * (LDS / global float atomics), as in torchvision. */
+ * four taps (torchvision roi_align_backward); boxes get no gradient.  Planes that fit LDS are summed in RoI order by
+ * one workgroup per (image, channel chunk): bit-identical from run to run; larger planes and small batches add partial
+ * sums with global float atomics, whose order is not fixed (as in torchvision).  grad_out must be finite: the 7 x 7
+ * products run as dense matrix products, so one Inf / NaN of a RoI's gradient reaches every cell of that RoI's footprint
+ * (torchvision: only the cells the bin's samples touch) and up to three cells beside it in the same rows. */
 int frcnn_roi_align_batched_backward_f32(const float *grad_out, int B, int C, int H, int W,
                                          const float *props, const int32_t *count, int P, int pooled_h,
                                          int pooled_w, float spatial_scale, int sampling_ratio, int level,
