@@ -437,7 +437,11 @@ typedef __attribute__((address_space(3))) void rcl_lds_void;
 
 // One fill = four cells: lane l brings bytes [16 (l % 16), +16) of cell l / 16 (vlane = that cell's and piece's byte
 // offset: cells are cell_bytes apart, 256 in the blocked copy where a fill is one contiguous KiB); in LDS the four
-// cells are contiguous whatever the layout.
+// cells are contiguous whatever the layout.  A ring row is always 16 cells from the first tap's cell on, which can run
+// past the end of the map's row: inside the image those are the next row's first cells (fetched, never read by a
+// tap); past the end of the image's slice -- at the last row of the last image, past the end of the tensor -- the
+// buffer's range check, which on gfx950 covers per-lane offset + scalar offset (tools/ubench/buffer_range.hip), returns
+// zeros without touching memory: the descriptor's size is exactly the rest of the image's slice.
 __device__ __forceinline__ void rcl_fill_row(__amdgpu_buffer_rsrc_t rsrc, float *slot, int vlane, int off, int cell_bytes)
 {
 #pragma unroll
