@@ -469,7 +469,9 @@ __device__ __forceinline__ void rcl_ring_row(float (&acc)[49], const float *slot
     for (int t = 1; t < NX; ++t)
 #pragma unroll
         for (int p = 0; p < 7; ++p) rcl_fma(T[p], wx[p * 4 + t], v[p * NX + t]);
-    // the taps are in registers (T depends on them): the slot may be refilled with the row two further on
+    // the taps are in registers (T depends on them; the explicit wait makes that independent of how the compiler
+    // orders the contraction against the fills): the slot may be refilled with the row two further on
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int kn = k + 2;
     rcl_fill_row(rsrc, refill, vlane + (kn < nrows ? 0 : RCL_OOB),
                  __builtin_amdgcn_readlane(v_rows, min(kn, 63)) * row_bytes + c0_bytes, cell_bytes);
